@@ -1,0 +1,135 @@
+"""Pins the CPU restatement (oracle/) against vectors captured from the reference itself.
+
+CPU-only.  The goldens were produced by tests/golden/gen_golden.py running the reference's
+own PPO.update / select_action / decay_action_std (PPO.py:124-258).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, UPDATE_CASES, case_params, load_case, max_abs, rel_err
+from oracle import ppo_oracle as O
+
+# tolerances (north star: 1e-5 relative on returns/advantages/log-probs/loss, 1e-4 on params)
+TOL_REL = 1e-5
+TOL_PARAM = 1e-4
+
+
+def _run(d, K, record=False):
+    cont = bool(d["continuous"])
+    std = float(d["action_std"]) if cont else None
+    P = case_params(d)
+    st = O.adam_init(P)
+    rec = O.update(P, st, d["states"], d["actions"], d["old_logprobs"], d["old_values"],
+                   d["rewards"], d["terminals"], float(d["gamma"]), float(d["eps_clip"]), K,
+                   float(d["lr_actor"]), float(d["lr_critic"]), cont, std, record=record)
+    return P, st, rec
+
+
+@pytest.mark.parametrize("name", UPDATE_CASES)
+def test_first_epoch_intermediates(name):
+    d = load_case(name)
+    K = int(d["K_list"][0])
+    P, st, rec = _run(d, K, record=True)
+    # returns: fp64 accumulation is the same serial recurrence -> exact; fp32 rounding exact
+    assert max_abs(rec["returns64"], d["returns64"]) == 0.0
+    assert np.array_equal(rec["returns32"], d["returns32"])
+    assert rel_err(rec["ret_mean"], d["ret_mean"]) < TOL_REL
+    assert rel_err(rec["ret_std"], d["ret_std"]) < TOL_REL
+    assert rel_err(rec["returns_norm"], d["returns_norm"]) < TOL_REL
+    assert rel_err(rec["advantages"], d["advantages"]) < TOL_REL
+    assert rel_err(rec["logprobs_e1"], d["logprobs_e1"]) < TOL_REL
+    assert rel_err(rec["state_values_e1"], d["state_values_e1"]) < TOL_REL
+    assert rel_err(rec["entropy_e1"], d["entropy_e1"]) < TOL_REL
+    assert rel_err(rec["ratios_e1"], d["ratios_e1"]) < TOL_REL
+    assert rel_err(rec["loss_e1"], d["loss_per_sample_e1"]) < TOL_REL
+    assert rel_err(rec["loss_mean_e1"], d["loss_mean_e1"]) < TOL_REL
+    for k in O.PARAM_KEYS:
+        g = d["grad_e1/" + k]
+        # gradients: relative to the largest component of the tensor (tiny components are
+        # rounding noise of an fp32 sum over T samples in both implementations)
+        assert rel_err(rec["grads_e1"][k], g, floor=float(np.abs(g).max())) < 1e-4, k
+    for k in O.PARAM_KEYS:
+        assert max_abs(P[k], d[f"K{K}/param/{k}"]) < TOL_PARAM, k
+        assert max_abs(st["m"][k], d[f"K{K}/exp_avg/{k}"]) < 1e-6, k
+    assert st["step"] == int(d[f"K{K}/step"])
+
+
+@pytest.mark.parametrize("name", UPDATE_CASES)
+def test_params_after_k_epochs(name):
+    d = load_case(name)
+    for K in d["K_list"][1:]:
+        K = int(K)
+        P, st, rec = _run(d, K)
+        # K<=4: 1e-4.  K=30/80: summation-order noise is amplified by Adam's sign-like first
+        # steps; two fp32 CPU implementations (torch vs numpy) already differ by ~1.2e-4 here.
+        tol = TOL_PARAM if K <= 4 else 5e-4
+        worst = max(max_abs(P[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
+        assert worst < tol, (K, worst)
+        assert rel_err(rec["loss_mean_all"], d[f"K{K}/loss_mean_all"]) < 1e-4
+        assert st["step"] == K
+
+
+def test_scan_cases():
+    d = np.load(os.path.join(GOLDEN, "scan_cases.npz"))
+    for i in range(int(d["n_cases"])):
+        r64 = O.returns_scan(d[f"{i}/rewards"], d[f"{i}/terminals"], float(d[f"{i}/gamma"]))
+        assert max_abs(r64, d[f"{i}/returns64"]) == 0.0, i
+        r32, mean, std, norm = O.normalize_returns(r64)
+        assert np.array_equal(r32, d[f"{i}/returns32"]), i
+        assert rel_err(mean, d[f"{i}/ret_mean"], floor=float(np.abs(r32).mean())) < TOL_REL, i
+        assert rel_err(std, d[f"{i}/ret_std"]) < TOL_REL, i
+        assert rel_err(norm, d[f"{i}/returns_norm"]) < TOL_REL, i
+
+
+def test_scan_rows_equals_flat_with_row_end_terminals():
+    rng = np.random.default_rng(0)
+    N, T = 7, 33
+    r = rng.standard_normal((N, T)).astype(np.float32).astype(np.float64)
+    term = rng.random((N, T)) < 0.1
+    rows = O.returns_scan_rows(r, term, 0.97)
+    forced = term.copy()
+    forced[:, -1] = True
+    flat = O.returns_scan(r.reshape(-1), forced.reshape(-1), 0.97).reshape(N, T)
+    # a terminal on the last step of a row resets the carry BEFORE that step, which is what
+    # a fresh row start (carry 0) does as well
+    assert np.array_equal(rows, flat)
+
+
+def test_decay_sequence():
+    with open(os.path.join(GOLDEN, "decay_sequence.json")) as f:
+        g = json.load(f)
+    s = g["std"][0]
+    for want, var in zip(g["std"][1:], g["var"][1:]):
+        s = O.decay_action_std(s, g["rate"], g["min"])
+        assert s == want
+        v, _ = O.action_sigma(s)
+        assert np.float32(var[0]) == v
+    s = g["std2"][0]
+    for want in g["std2"][1:]:
+        s = O.decay_action_std(s, g["rate2"], g["min2"])
+        assert s == want
+
+
+def test_shipped_checkpoints_forward():
+    d = np.load(os.path.join(GOLDEN, "checkpoints.npz"))
+    for env in d["envs"]:
+        P = {k[len(env) + 7:]: d[k] for k in d.files if k.startswith(f"{env}/param/")}
+        assert sorted(P) == sorted(O.PARAM_KEYS)
+        cont = bool(d[f"{env}/continuous"])
+        logp, V, ent, _ = O.evaluate(P, d[f"{env}/states"], d[f"{env}/actions"], cont, 0.6)
+        assert rel_err(V, d[f"{env}/critic_out"]) < TOL_REL, env
+        assert rel_err(logp, d[f"{env}/logprobs"]) < TOL_REL, env
+        assert rel_err(ent, d[f"{env}/entropy"]) < TOL_REL, env
+
+
+def test_param_packing_roundtrip():
+    d = load_case("c2_lunarlander")
+    P = case_params(d)
+    flat = O.flatten_params(P)
+    assert flat.shape[0] == 9797
+    Q = O.unflatten_params(flat, 8, 4)
+    for k in O.PARAM_KEYS:
+        assert np.array_equal(P[k], Q[k])
