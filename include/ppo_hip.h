@@ -1,0 +1,146 @@
+/*
+ * ppo_hip.h - C ABI of the MI355X (gfx950) PPO engine.
+ *
+ * The reference (Katherine121/PPO, a fork of PPO-PyTorch) has no FFI: its hot path is the Python
+ * class surface of PPO.py.  Each entry point below replaces the arithmetic of one piece of that
+ * file; the citation after "replaces" names it.  The host-side mirror of the class surface
+ * (ppo_amd/ppo.py) is the only caller.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t, or a negative PPO_E_* code;
+ *   - all pointers are DEVICE pointers borrowed from the caller (no ownership is taken) unless the
+ *     parameter name ends in _host;
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*); nothing here
+ *     synchronises, allocates or frees device memory;
+ *   - thread-compatible, not thread-safe: one workspace per concurrent caller.
+ *
+ * Parameter vector layout (P floats, fp32, state_dict order of ActorCritic, PPO.py:49-73):
+ *   actor.0.weight[64,S] actor.0.bias[64] actor.2.weight[64,64] actor.2.bias[64]
+ *   actor.4.weight[A,64] actor.4.bias[A]  then the same six tensors of the critic with A -> 1.
+ *   Every weight is [out,in] row-major, exactly as torch.nn.Linear stores it.
+ */
+#ifndef PPO_HIP_H
+#define PPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPO_HIDDEN 64          /* hidden width of both MLPs, PPO.py:50-52,68-70 */
+#define PPO_MAX_STATE_DIM 63   /* S + 1 (bias column) must fit two 32-wide MFMA tiles */
+#define PPO_MAX_ACTION_DIM 8
+
+#define PPO_E_BADARG (-1)      /* shape / pointer / size outside what the kernels assume */
+#define PPO_E_WORKSPACE (-2)   /* workspace smaller than ppo_workspace_bytes() */
+#define PPO_E_UNSUPPORTED (-3) /* S or A beyond PPO_MAX_* */
+
+/* ABI version of this header (bumped on any signature change). */
+int ppo_hip_abi_version(void);
+
+/* Human-readable text for a return code of any function here. */
+const char* ppo_hip_strerror(int code);
+
+/* Number of parameters P for (S, A); n_actor_out receives the size of the actor block. */
+int64_t ppo_param_count(int state_dim, int action_dim, int64_t* n_actor_out);
+
+/* Bytes of scratch the functions taking (workspace, workspace_bytes) need for buffers of up to
+ * max_samples samples. */
+size_t ppo_workspace_bytes(int state_dim, int action_dim, int64_t max_samples);
+
+/* ---- rollout -------------------------------------------------------------------------------
+ * Batched ActorCritic.act for n states at once.  replaces: PPO.py:86-100 (act) as called by
+ * PPO.select_action, PPO.py:175-198.  Samples an action per state from Categorical(softmax) or
+ * N(tanh(mean), diag(action_var)), and writes action, log-prob of that action, and the critic
+ * value.  Randomness: Philox4x32-10 keyed by `seed`, counter (rng_offset, state index) - the
+ * reference's action stream (torch global CPU generator) is not reproducible and not a parity
+ * target; log-prob and value for the (state, action) pairs written ARE.
+ *   actions: int32[n] (discrete) or float[n, A] (continuous).
+ *   action_var: fp32 value of std*std (PPO.py:46); ignored when continuous == 0.
+ */
+int ppo_act(const float* params, int state_dim, int action_dim, int continuous, float action_var,
+            const float* states, int64_t n, uint64_t seed, uint64_t rng_offset,
+            void* actions, float* logprobs, float* values, void* stream);
+
+/* ActorCritic.evaluate forward only: log-prob of GIVEN actions, value, entropy per sample.
+ * replaces: PPO.py:102-121.  Any of the three outputs may be NULL. */
+int ppo_evaluate(const float* params, int state_dim, int action_dim, int continuous,
+                 float action_var, const float* states, const void* actions, int64_t n,
+                 float* logprobs, float* values, float* entropy, void* stream);
+
+/* ---- returns -------------------------------------------------------------------------------
+ * Monte-Carlo discounted returns with terminal resets over ONE flat sequence, fp64 carry,
+ * rounded once to fp32, plus the moments of the rounded returns.
+ * replaces: PPO.py:202-211 (reverse loop + torch.tensor(..., float32)) and the reductions of
+ * PPO.py:212.
+ *   rewards: float[n] when rewards_are_f64 == 0, double[n] otherwise (the reference accumulates
+ *   Python floats, i.e. doubles).  terminals: uint8[n].
+ *   moments_out: double[3] = {count, mean, M2 = sum (x-mean)^2} of the fp32 returns.
+ */
+int ppo_returns_scan_flat(const void* rewards, int rewards_are_f64, const uint8_t* terminals,
+                          int64_t n, double gamma, float* returns_out, double* moments_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same recurrence for a time-major [n_steps, n_envs] rollout of independent envs: column e is
+ * env e's trajectory; a column starts from carry 0 at its last step exactly as the flat buffer
+ * does at its end (PPO.py:203).  Equals the flat scan of the env-major concatenation with the
+ * last step of every env flagged terminal. */
+int ppo_returns_scan_rows(const float* rewards_tn, const uint8_t* terminals_tn, int64_t n_steps,
+                          int64_t n_envs, double gamma, float* returns_tn, double* moments_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Normalised returns and advantages from device-resident moments (no host round trip):
+ *   std = sqrt(M2/(count-1)); returns_norm = (returns - mean) / (std + 1e-7);
+ *   advantages = returns_norm - old_values.
+ * replaces: PPO.py:212 (elementwise part) and PPO.py:221.  returns_norm may alias returns. */
+int ppo_normalize_advantage(const float* returns, const float* old_values, int64_t n,
+                            const double* moments, float* returns_norm, float* advantages,
+                            void* stream);
+
+/* ---- update --------------------------------------------------------------------------------
+ * One epoch of evaluate + clipped-surrogate loss + backward over n_local samples, leaving
+ * per-workgroup gradient partials in the workspace.  replaces: PPO.py:227-244 (evaluate, ratio,
+ * surr1/surr2, loss, loss.mean().backward()).  Gradients are those of
+ *   (1/n_global) * sum_t [ -min(r_t A_t, clamp(r_t,1-eps,1+eps) A_t) + 0.5 (V_t-R_t)^2 - 0.01 H_t ]
+ * so that the sum over data-parallel shards is the reference's gradient.
+ * Optional per-sample outputs (each may be NULL): out_logprobs, out_values, out_entropy,
+ * out_surrogate (= min(surr1, surr2)).
+ */
+int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_dim, int continuous,
+                     float action_var, const float* states, const void* actions,
+                     const float* old_logprobs, const float* advantages, const float* returns_norm,
+                     int64_t n_local, int64_t n_global, float eps_clip,
+                     float* out_logprobs, float* out_values, float* out_entropy,
+                     float* out_surrogate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Deterministic fixed-order sum of the partials left by ppo_epoch_fwdbwd.
+ * grad_out: float[P + 2]; grad_out[P] = shard's sum of (-min(..) - 0.01 H)/n_global,
+ * grad_out[P+1] = shard's 0.5*sum (V-R)^2 / n_global; their sum over shards is loss.mean(). */
+int ppo_grad_reduce(int state_dim, int action_dim, const void* workspace, size_t workspace_bytes,
+                    float* grad_out, void* stream);
+
+/* torch.optim.Adam step (no weight decay, no amsgrad) with two learning-rate groups.
+ * replaces: PPO.py:139-142,245 (torch/optim/adam.py single-tensor path).  `step` is the 1-based
+ * count of optimizer steps including this one (it persists across update() calls).
+ * loss_out (may be NULL): receives grad[n_params] + grad[n_params+1], i.e. loss.mean() of the
+ * epoch whose (all-reduced) gradient vector this is; `grad` therefore holds n_params + 2 floats. */
+int ppo_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t n_params, int64_t n_actor, int64_t step, double lr_actor,
+                  double lr_critic, double beta1, double beta2, double eps, float* loss_out,
+                  void* stream);
+
+/* ---- synthetic vectorised environment (measurement harness) ---------------------------------
+ * One lockstep step of n_envs synthetic envs: observations ~ N(0,1), reward 1.0 (kind 0) or
+ * ~N(0,1) (kind 1), terminal ~ Bernoulli(p_terminal) or, when p_terminal < 0, exactly at steps
+ * with (step % horizon) == horizon-1.  No counterpart in the reference (its envs are gym's,
+ * train.py:53); this stands in for env.step (train.py:177) in bench.py and the tests. */
+int ppo_synth_env_step(float* states_out, float* rewards_out, uint8_t* terminals_out,
+                       int64_t n_envs, int state_dim, int reward_kind, float p_terminal,
+                       int64_t step, int64_t horizon, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPO_HIP_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libppo_hip.so (the C ABI declared in include/ppo_hip.h).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch  # noqa: F401  (loads the HIP runtime the library binds to before dlopen)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libppo_hip.so")
+ABI_VERSION = 1
+
+_SIGNATURES = {
+    "ppo_hip_abi_version": (c_int, []),
+    "ppo_hip_strerror": (c_char_p, [c_int]),
+    "ppo_param_count": (c_int64, [c_int, c_int, ctypes.POINTER(c_int64)]),
+    "ppo_workspace_bytes": (c_size_t, [c_int, c_int, c_int64]),
+    "ppo_act": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_uint64,
+                        c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppo_evaluate": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int64,
+                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppo_returns_scan_flat": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_double, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ppo_returns_scan_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ppo_normalize_advantage": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
+    "ppo_epoch_fwdbwd": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ppo_grad_reduce": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "ppo_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                              c_double, c_double, c_double, c_double, c_double, c_void_p,
+                              c_void_p]),
+    "ppo_synth_env_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
+                                   c_int64, c_int64, c_uint64, c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """The loaded library (dlopen on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m ppo_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.ppo_hip_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"libppo_hip.so ABI {got} != binding {ABI_VERSION}; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError(f"libppo_hip call failed ({code}): "
+                           f"{lib().ppo_hip_strerror(code).decode()}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, or NULL for None."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,306 @@
+// Shared device code of the gfx950 PPO kernels: parameter layout, the wave-level MLP tile
+// (fp32 MFMA, sample-on-lane orientation), the distribution heads, Philox.
+//
+// Orientation used everywhere: one wave owns a tile of 32 samples.  Lane l holds sample
+// c = l & 31; h = l >> 5 selects which half of the hidden units the lane's registers carry.
+// A 64-unit activation vector of the 32 samples is two 32x32 MFMA accumulator tiles
+// (f32x16 t[2]): register r of tile t on lane (c, h) is unit 32*t + rho(r, h) of sample c, with
+//   rho(r, h) = (r & 3) + 8 * (r >> 2) + 4 * h
+// (the C/D layout of v_mfma_f32_32x32x2_f32).  Because the B operand of that instruction wants
+// B[k = h][j = c], an accumulator register is directly the B operand of the next layer's k-step
+// {rho(r,0), rho(r,1)}: activations never leave registers between layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ppo_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define HID PPO_HIDDEN
+#define TILE_M 32   // samples per wave tile
+#define STG_LD 65   // row stride (floats) of the per-wave transposition buffers: odd => conflict-free
+
+#define HEAD_CATEGORICAL 0
+#define HEAD_GAUSSIAN 1
+#define HEAD_VALUE 2
+
+#define LOG_2PI_F 1.8378770664093453f
+#define EPS_PROB_F 1.1920928955078125e-07f  // finfo(float32).eps, torch/distributions/utils.py:121
+
+// ------------------------------------------------------------------ parameter layout
+struct NetLayout {  // offsets (floats) of one MLP inside the flat parameter vector
+    int w1, b1, w2, b2, w3, b3, n;
+};
+
+__host__ __device__ inline NetLayout net_layout(int base, int S, int out) {
+    NetLayout L;
+    L.w1 = base;
+    L.b1 = L.w1 + HID * S;
+    L.w2 = L.b1 + HID;
+    L.b2 = L.w2 + HID * HID;
+    L.w3 = L.b2 + HID;
+    L.b3 = L.w3 + out * HID;
+    L.n = L.b3 + out - base;
+    return L;
+}
+
+__host__ __device__ inline int n_actor_params(int S, int A) { return net_layout(0, S, A).n; }
+__host__ __device__ inline int n_critic_params(int S) { return net_layout(0, S, 1).n; }
+
+__device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ tanh
+// |x| < 0.625: odd polynomial (Cephes tanhf coefficients, < 1 ulp there);
+// otherwise 1 - 2/(exp(2|x|)+1) with the accurate expf.  Max error ~1.5 ulp.
+__device__ __forceinline__ float tanh_f32(float x) {
+    const float ax = fabsf(x);
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = fmaf(p, z, 2.06390887954e-2f);
+    p = fmaf(p, z, -5.37397155531e-2f);
+    p = fmaf(p, z, 1.33314422036e-1f);
+    p = fmaf(p, z, -3.33332819422e-1f);
+    const float small = fmaf(p * z, x, x);
+    const float e = __expf(2.0f * ax);
+    const float big = copysignf(1.0f - 2.0f / (e + 1.0f), x);
+    return ax < 0.625f ? small : big;
+}
+
+__device__ __forceinline__ f32x16 tanh16(f32x16 v) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = tanh_f32(v[r]);
+    return o;
+}
+
+// ------------------------------------------------------------------ LDS image of one MLP
+// w1t: [2*KS1][64]  row k (< S: input k; == S: bias b1; > S: zero), column = hidden unit
+// w2t: [64][64]     [in][out]  (forward A operand: lanes run over `out`)
+// w2n: [64][64]     [out][in]  (dgrad A operand: lanes run over `in`); absent for forward-only
+// b2 : [64], w3: [AOUT][64] (rows >= A zero), b3: [AOUT]
+struct NetLds {
+    float* w1t;
+    float* w2t;
+    float* w2n;
+    float* b2;
+    float* w3;
+    float* b3;
+};
+
+__host__ __device__ inline int ks1_of(int S) { return (S + 2) / 2; }  // ceil((S+1)/2) k-steps
+
+__host__ __device__ inline int net_lds_floats(int S, int aout, bool bwd) {
+    return 2 * ks1_of(S) * HID + HID * HID * (bwd ? 2 : 1) + HID + aout * HID + ((aout + 3) & ~3);
+}
+
+__device__ inline NetLds carve_net_lds(float* base, int S, int aout, bool bwd) {
+    NetLds L;
+    L.w1t = base;
+    L.w2t = L.w1t + 2 * ks1_of(S) * HID;
+    L.w2n = bwd ? L.w2t + HID * HID : nullptr;
+    L.b2 = L.w2t + HID * HID * (bwd ? 2 : 1);
+    L.w3 = L.b2 + HID;
+    L.b3 = L.w3 + aout * HID;
+    return L;
+}
+
+// Block-wide fill; caller synchronises afterwards.
+__device__ inline void fill_net_lds(const NetLds& L, const float* __restrict__ params,
+                                    const NetLayout& P, int S, int A, int aout, bool bwd) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int rows1 = 2 * ks1_of(S);
+    for (int i = tid; i < rows1 * HID; i += nt) {
+        const int k = i >> 6, o = i & 63;
+        float v = 0.f;
+        if (k < S) v = params[P.w1 + o * S + k];
+        else if (k == S) v = params[P.b1 + o];
+        L.w1t[i] = v;
+    }
+    for (int i = tid; i < HID * HID; i += nt) {
+        const float v = params[P.w2 + i];  // W2[out = i>>6][in = i&63]
+        L.w2t[(i & 63) * HID + (i >> 6)] = v;
+        if (bwd) L.w2n[i] = v;
+    }
+    for (int i = tid; i < HID; i += nt) L.b2[i] = params[P.b2 + i];
+    for (int i = tid; i < aout * HID; i += nt) L.w3[i] = (i >> 6) < A ? params[P.w3 + i] : 0.f;
+    for (int i = tid; i < aout; i += nt) L.b3[i] = i < A ? params[P.b3 + i] : 0.f;
+}
+
+// ------------------------------------------------------------------ forward of one 32-sample tile
+// states: [n, S] row-major; m = this lane's sample; valid = m < n.
+__device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __restrict__ states,
+                                             int S, int64_t m, bool valid, int c, int h,
+                                             f32x16 (&H1)[2], f32x16 (&H2)[2]) {
+    f32x16 z0 = {0}, z1 = {0};
+    const int ks1 = ks1_of(S);
+    for (int s = 0; s < ks1; ++s) {
+        const int k = 2 * s + h;
+        float b = (k == S) ? 1.0f : 0.0f;          // ones column carries the bias
+        if (k < S && valid) b = states[m * S + k];
+        const float a0 = L.w1t[k * HID + c];
+        const float a1 = L.w1t[k * HID + 32 + c];
+        z0 = mfma32(a0, b, z0);
+        z1 = mfma32(a1, b, z1);
+    }
+    H1[0] = tanh16(z0);
+    H1[1] = tanh16(z1);
+    f32x16 y0, y1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        y0[r] = L.b2[rho(r, h)];
+        y1[r] = L.b2[32 + rho(r, h)];
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = 32 * st + rho(r, h);
+            const float b = H1[st][r];
+            const float a0 = L.w2t[k * HID + c];
+            const float a1 = L.w2t[k * HID + 32 + c];
+            y0 = mfma32(a0, b, y0);
+            y1 = mfma32(a1, b, y1);
+        }
+    }
+    H2[0] = tanh16(y0);
+    H2[1] = tanh16(y1);
+}
+
+// o[a] = b3[a] + sum_u W3[a][u] * H2[u]; each lane sums its 32 units, the two halves are added.
+template <int AOUT>
+__device__ __forceinline__ void out_layer(const NetLds& L, int A, const f32x16 (&H2)[2], int h,
+                                          float (&o)[AOUT]) {
+#pragma unroll
+    for (int a = 0; a < AOUT; ++a) {
+        float acc = 0.f;
+        if (a < A) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[a * HID + 32 * t + 8 * q + 4 * h]);
+                    acc = fmaf(w.x, H2[t][4 * q + 0], acc);
+                    acc = fmaf(w.y, H2[t][4 * q + 1], acc);
+                    acc = fmaf(w.z, H2[t][4 * q + 2], acc);
+                    acc = fmaf(w.w, H2[t][4 * q + 3], acc);
+                }
+            }
+            acc += __shfl_xor(acc, 32);
+            acc += L.b3[a];
+        }
+        o[a] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ heads
+// Categorical over softmax probabilities, restating torch/distributions/categorical.py:71
+// (renormalise), utils.py:121-137 (logits = log(clamp(probs, eps, 1-eps))), :150-161.
+template <int AOUT>
+struct CatOut {
+    float q[AOUT];     // renormalised probabilities
+    float L[AOUT];     // clamped log-probabilities
+    float pass[AOUT];  // 1 where the clamp passes gradient (closed interval), else 0
+    float ent;
+};
+
+template <int AOUT>
+__device__ __forceinline__ void categorical_head(const float (&o)[AOUT], int A, CatOut<AOUT>& out) {
+    float mx = o[0];
+#pragma unroll
+    for (int a = 1; a < AOUT; ++a) if (a < A) mx = fmaxf(mx, o[a]);
+    float e[AOUT], s = 0.f;
+#pragma unroll
+    for (int a = 0; a < AOUT; ++a) { e[a] = a < A ? expf(o[a] - mx) : 0.f; s += e[a]; }
+    float s2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < AOUT; ++a) { e[a] = e[a] / s; s2 += e[a]; }
+    float ent = 0.f;
+#pragma unroll
+    for (int a = 0; a < AOUT; ++a) {
+        const float q = e[a] / s2;
+        const float qc = fminf(fmaxf(q, EPS_PROB_F), 1.0f - EPS_PROB_F);
+        const float L = logf(qc);
+        out.q[a] = q;
+        out.L[a] = L;
+        out.pass[a] = (q >= EPS_PROB_F && q <= 1.0f - EPS_PROB_F) ? 1.f : 0.f;
+        if (a < A) ent += L * q;
+    }
+    out.ent = -ent;
+}
+
+// Diagonal Gaussian around tanh(o): torch/distributions/multivariate_normal.py:255-273 with
+// scale_tril = diag(sqrt(var)) (:193).
+template <int AOUT>
+struct GaussOut {
+    float mu[AOUT];
+    float zed[AOUT];  // (a - mu) / sigma
+    float logp, ent, sigma;
+};
+
+template <int AOUT>
+__device__ __forceinline__ void gaussian_head(const float (&o)[AOUT], int A, float action_var,
+                                              const float (&act)[AOUT], GaussOut<AOUT>& out) {
+    const float sigma = sqrtf(action_var);
+    const float ls = logf(sigma);
+    float M = 0.f, hld = 0.f;
+#pragma unroll
+    for (int a = 0; a < AOUT; ++a) {
+        if (a < A) {
+            const float mu = tanh_f32(o[a]);
+            const float z = (act[a] - mu) / sigma;
+            out.mu[a] = mu;
+            out.zed[a] = z;
+            M += z * z;
+            hld += ls;
+        } else {
+            out.mu[a] = 0.f;
+            out.zed[a] = 0.f;
+        }
+    }
+    out.sigma = sigma;
+    out.logp = -0.5f * ((float)A * LOG_2PI_F + M) - hld;
+    out.ent = 0.5f * (float)A * (1.0f + LOG_2PI_F) + hld;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct Philox {
+    uint32_t c[4], k[2];
+    __device__ Philox(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo) {
+        k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
+        c[0] = (uint32_t)ctr_lo; c[1] = (uint32_t)(ctr_lo >> 32);
+        c[2] = (uint32_t)ctr_hi; c[3] = (uint32_t)(ctr_hi >> 32);
+    }
+    __device__ void next(uint32_t (&out)[4]) {
+        uint32_t x0 = c[0], x1 = c[1], x2 = c[2], x3 = c[3], k0 = k[0], k1 = k[1];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * x0;
+            const uint64_t p1 = (uint64_t)0xCD9E8D57u * x2;
+            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0;
+            const uint32_t y1 = (uint32_t)p1;
+            const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1;
+            const uint32_t y3 = (uint32_t)p0;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+        if (++c[0] == 0) if (++c[1] == 0) if (++c[2] == 0) ++c[3];
+    }
+};
+
+__device__ __forceinline__ float u01(uint32_t x) {  // (0, 1]
+    return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    const float th = 6.283185307179586f * u01(b);
+    n0 = r * cosf(th);
+    n1 = r * sinf(th);
+}

@@ -1,0 +1,359 @@
+// Monte-Carlo return scan, moments and normalisation (HBM-bound stage of PPO.update).
+//
+// The recurrence of PPO.py:204-208 is R_t = r_t + gamma * (terminal_t ? 0 : R_{t+1}) in fp64.
+// Each step is the affine map x -> b + a*x with (a, b) = (terminal ? 0 : gamma, r); maps compose
+// associatively, so a flat sequence is scanned in three launches:
+//   1. every block composes the maps of its 2048 elements (wave shuffles + LDS)        -> aggregate
+//   2. one wave turns the block aggregates into the carry entering each block          -> carries
+//   3. every block re-composes, gives each thread the exact carry entering its 8 elements, and
+//      runs the reference's own serial recurrence (separate multiply and add, as Python does)
+//      on them; it rounds to fp32 once (PPO.py:211) and leaves fp64 moments of the rounded values.
+// Only the carries go through re-associated arithmetic (relative error ~1e-16 before the fp32
+// rounding); everything inside a thread's 8 elements is the reference's operation order.
+#include "ppo_common.h"
+
+#define SCAN_BLOCK 256
+#define SCAN_E 8
+#define SCAN_CHUNK (SCAN_BLOCK * SCAN_E)
+
+struct Aff {  // x -> b + a * x
+    double a, b;
+};
+
+__device__ __forceinline__ Aff compose(const Aff& l, const Aff& r) {  // l after r (l is to the left)
+    Aff o;
+    o.a = l.a * r.a;
+    o.b = l.b + l.a * r.b;
+    return o;
+}
+
+__device__ __forceinline__ Aff shfl_down_aff(const Aff& v, int off) {
+    Aff o;
+    o.a = __shfl_down(v.a, off);
+    o.b = __shfl_down(v.b, off);
+    return o;
+}
+
+// inclusive suffix composition over the 64 lanes: lane i gets F_i o F_{i+1} o ... o F_63
+__device__ __forceinline__ Aff wave_suffix(Aff v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Aff o = shfl_down_aff(v, off);
+        if (lane + off < 64) v = compose(v, o);
+    }
+    return v;
+}
+
+struct Mom {  // count, mean, M2
+    double n, mean, m2;
+};
+
+__device__ __forceinline__ Mom merge(const Mom& x, const Mom& y) {  // Chan et al. pairwise merge
+    if (y.n == 0.0) return x;
+    if (x.n == 0.0) return y;
+    Mom o;
+    o.n = x.n + y.n;
+    const double d = y.mean - x.mean;
+    o.mean = x.mean + d * (y.n / o.n);
+    o.m2 = x.m2 + y.m2 + d * d * (x.n * y.n / o.n);
+    return o;
+}
+
+__device__ __forceinline__ Mom block_merge(Mom v, Mom* lds /* >= 4 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Mom o;
+        o.n = __shfl_down(v.n, off);
+        o.mean = __shfl_down(v.mean, off);
+        o.m2 = __shfl_down(v.m2, off);
+        if (lane + off < 64) v = merge(v, o);
+    }
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    Mom t = lds[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = merge(t, lds[w]);
+    return t;
+}
+
+template <typename RT>
+__device__ __forceinline__ void load_elems(const RT* __restrict__ rewards,
+                                           const uint8_t* __restrict__ terminals, int64_t base,
+                                           int64_t n, double (&r)[SCAN_E], bool (&term)[SCAN_E]) {
+#pragma unroll
+    for (int j = 0; j < SCAN_E; ++j) {
+        const int64_t i = base + j;
+        const bool ok = i < n;
+        r[j] = ok ? (double)rewards[i] : 0.0;
+        term[j] = ok ? terminals[i] != 0 : false;
+    }
+}
+
+// composite of one thread's elements: maps carry at the chunk's end to R at its first element.
+// Out-of-range elements are the identity (a=1,b=0).
+__device__ __forceinline__ Aff thread_aff(const double (&r)[SCAN_E], const bool (&term)[SCAN_E],
+                                          int64_t base, int64_t n, double gamma) {
+    Aff f;
+    f.a = 1.0;
+    f.b = 0.0;
+#pragma unroll
+    for (int j = SCAN_E - 1; j >= 0; --j) {
+        if (base + j < n) {
+            const double a = term[j] ? 0.0 : gamma;
+            f.b = r[j] + a * f.b;
+            f.a = a * f.a;
+        }
+    }
+    return f;
+}
+
+template <typename RT>
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_flat_reduce(const RT* __restrict__ rewards,
+                                                               const uint8_t* __restrict__ terminals,
+                                                               int64_t n, double gamma,
+                                                               Aff* __restrict__ block_aff) {
+    __shared__ Aff wav[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_E;
+    double r[SCAN_E];
+    bool term[SCAN_E];
+    load_elems(rewards, terminals, base, n, r, term);
+    const Aff s = wave_suffix(thread_aff(r, term, base, n, gamma), lane);
+    if (lane == 0) wav[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Aff t = wav[0];
+        for (int w = 1; w < SCAN_BLOCK / 64; ++w) t = compose(t, wav[w]);
+        block_aff[blockIdx.x] = t;
+    }
+}
+
+// One wave: carry entering block b (the return just right of its last element) for all blocks.
+__global__ __launch_bounds__(64) void scan_flat_carries(const Aff* __restrict__ block_aff, int nb,
+                                                        double* __restrict__ carries) {
+    const int lane = threadIdx.x;
+    const int per = (nb + 63) / 64;
+    const int lo = lane * per, hi = min(nb, lo + per);
+    Aff f;
+    f.a = 1.0;
+    f.b = 0.0;
+    for (int b = hi - 1; b >= lo; --b) f = compose(block_aff[b], f);  // maps carry at hi to R at lo
+    const Aff s = wave_suffix(f, lane);
+    Aff x = shfl_down_aff(s, 1);  // composition of everything right of this lane's segment
+    if (lane == 63) { x.a = 1.0; x.b = 0.0; }
+    double carry = x.b;  // applied to the sequence end, where the return is 0 (PPO.py:203)
+    for (int b = hi - 1; b >= lo; --b) {
+        carries[b] = carry;
+        carry = block_aff[b].b + block_aff[b].a * carry;
+    }
+}
+
+template <typename RT>
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_flat_apply(const RT* __restrict__ rewards,
+                                                              const uint8_t* __restrict__ terminals,
+                                                              int64_t n, double gamma,
+                                                              const double* __restrict__ carries,
+                                                              float* __restrict__ returns,
+                                                              Mom* __restrict__ block_mom) {
+    __shared__ Aff wav[SCAN_BLOCK / 64];
+    __shared__ double wcarry[SCAN_BLOCK / 64];
+    __shared__ Mom mom_lds[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_E;
+    double r[SCAN_E];
+    bool term[SCAN_E];
+    load_elems(rewards, terminals, base, n, r, term);
+    const Aff s = wave_suffix(thread_aff(r, term, base, n, gamma), lane);
+    if (lane == 0) wav[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = carries[blockIdx.x];
+        for (int w = SCAN_BLOCK / 64 - 1; w >= 0; --w) {
+            wcarry[w] = c;
+            c = wav[w].b + wav[w].a * c;
+        }
+    }
+    __syncthreads();
+    Aff x = shfl_down_aff(s, 1);
+    if (lane == 63) { x.a = 1.0; x.b = 0.0; }
+    double d = x.b + x.a * wcarry[wave];
+    // the reference's own recurrence, one rounding per multiply and per add (Python floats)
+    float out[SCAN_E];
+    double sum = 0.0;
+    int cnt = 0;
+#pragma unroll
+    for (int j = SCAN_E - 1; j >= 0; --j) {
+        if (base + j < n) {
+            if (term[j]) d = 0.0;
+            d = __dadd_rn(r[j], __dmul_rn(gamma, d));
+            out[j] = (float)d;
+            sum += (double)out[j];
+            ++cnt;
+        }
+    }
+    Mom m;
+    m.n = (double)cnt;
+    m.mean = cnt ? sum / cnt : 0.0;
+    m.m2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_E; ++j) {
+        if (base + j < n) {
+            returns[base + j] = out[j];
+            const double dd = (double)out[j] - m.mean;
+            m.m2 += dd * dd;
+        }
+    }
+    const Mom bm = block_merge(m, mom_lds);
+    if (threadIdx.x == 0) block_mom[blockIdx.x] = bm;
+}
+
+// Time-major [n_steps, n_envs]: one thread per env walks its column backwards (exactly the
+// reference's serial order); loads and stores of a step are coalesced across envs.
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_rows_kernel(const float* __restrict__ rewards,
+                                                               const uint8_t* __restrict__ terminals,
+                                                               int64_t n_steps, int64_t n_envs,
+                                                               double gamma,
+                                                               float* __restrict__ returns,
+                                                               Mom* __restrict__ block_mom) {
+    __shared__ Mom mom_lds[SCAN_BLOCK / 64];
+    const int64_t e = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    Mom m;
+    m.n = 0.0;
+    m.mean = 0.0;
+    m.m2 = 0.0;
+    if (e < n_envs) {
+        double d = 0.0, shift = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int64_t t = n_steps - 1; t >= 0; --t) {
+            const int64_t i = t * n_envs + e;
+            if (terminals[i]) d = 0.0;
+            d = __dadd_rn((double)rewards[i], __dmul_rn(gamma, d));
+            const float o = (float)d;
+            returns[i] = o;
+            if (t == n_steps - 1) shift = (double)o;
+            const double y = (double)o - shift;
+            s1 += y;
+            s2 += y * y;
+        }
+        m.n = (double)n_steps;
+        m.mean = shift + s1 / m.n;
+        m.m2 = fmax(s2 - s1 * s1 / m.n, 0.0);
+    }
+    const Mom bm = block_merge(m, mom_lds);
+    if (threadIdx.x == 0) block_mom[blockIdx.x] = bm;
+}
+
+__global__ __launch_bounds__(256) void moments_finalize(const Mom* __restrict__ block_mom, int nb,
+                                                        double* __restrict__ out3) {
+    __shared__ Mom mom_lds[4];
+    Mom m;
+    m.n = 0.0;
+    m.mean = 0.0;
+    m.m2 = 0.0;
+    // contiguous segments keep the merge order equal to the sequence order
+    const int per = (nb + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(nb, lo + per);
+    for (int b = lo; b < hi; ++b) m = merge(m, block_mom[b]);
+    const Mom t = block_merge(m, mom_lds);
+    if (threadIdx.x == 0) {
+        out3[0] = t.n;
+        out3[1] = t.mean;
+        out3[2] = t.m2;
+    }
+}
+
+// PPO.py:212 (elementwise) + PPO.py:221.  fp32 arithmetic exactly as the reference's tensors:
+// mean and std are fp32 scalars, 1e-7 is added to the fp32 std, the division is IEEE.
+__global__ __launch_bounds__(256) void normalize_adv_kernel(const float* __restrict__ returns,
+                                                            const float* __restrict__ old_values,
+                                                            int64_t n,
+                                                            const double* __restrict__ moments,
+                                                            float* __restrict__ returns_norm,
+                                                            float* __restrict__ adv) {
+    const double cnt = moments[0];
+    const float mean = (float)moments[1];
+    const float stdv = (float)sqrt(moments[2] / fmax(cnt - 1.0, 1.0));
+    const float denom = stdv + 1e-7f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float rn = (returns[i] - mean) / denom;
+        returns_norm[i] = rn;
+        adv[i] = rn - old_values[i];
+    }
+}
+
+// ---------------------------------------------------------------------------- host side
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// workspace carve for the scan: [Aff nb][double nb][Mom nb]
+size_t ppo_scan_ws_bytes(int64_t n) {
+    const size_t nb = (size_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK) + 1;
+    const size_t nb_rows = (size_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK) + 1;
+    const size_t m = nb > nb_rows ? nb : nb_rows;
+    return align_up(m * sizeof(Aff), 256) + align_up(m * sizeof(double), 256) +
+           align_up(m * sizeof(Mom), 256);
+}
+
+extern "C" int ppo_returns_scan_flat(const void* rewards, int rewards_are_f64,
+                                     const uint8_t* terminals, int64_t n, double gamma,
+                                     float* returns_out, double* moments_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!rewards || !terminals || !returns_out || !moments_out || n <= 0 ||
+        n > ((int64_t)1 << 40))
+        return PPO_E_BADARG;
+    if (!workspace || workspace_bytes < ppo_scan_ws_bytes(n)) return PPO_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    char* w = (char*)workspace;
+    Aff* aff = (Aff*)w;
+    w += align_up((size_t)(nb + 1) * sizeof(Aff), 256);
+    double* carries = (double*)w;
+    w += align_up((size_t)(nb + 1) * sizeof(double), 256);
+    Mom* mom = (Mom*)w;
+    if (rewards_are_f64) {
+        scan_flat_reduce<double><<<nb, SCAN_BLOCK, 0, st>>>((const double*)rewards, terminals, n,
+                                                            gamma, aff);
+        scan_flat_carries<<<1, 64, 0, st>>>(aff, nb, carries);
+        scan_flat_apply<double><<<nb, SCAN_BLOCK, 0, st>>>((const double*)rewards, terminals, n,
+                                                           gamma, carries, returns_out, mom);
+    } else {
+        scan_flat_reduce<float><<<nb, SCAN_BLOCK, 0, st>>>((const float*)rewards, terminals, n,
+                                                           gamma, aff);
+        scan_flat_carries<<<1, 64, 0, st>>>(aff, nb, carries);
+        scan_flat_apply<float><<<nb, SCAN_BLOCK, 0, st>>>((const float*)rewards, terminals, n,
+                                                          gamma, carries, returns_out, mom);
+    }
+    moments_finalize<<<1, 256, 0, st>>>(mom, nb, moments_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ppo_returns_scan_rows(const float* rewards_tn, const uint8_t* terminals_tn,
+                                     int64_t n_steps, int64_t n_envs, double gamma,
+                                     float* returns_tn, double* moments_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!rewards_tn || !terminals_tn || !returns_tn || !moments_out || n_steps <= 0 ||
+        n_envs <= 0 || n_steps * n_envs > ((int64_t)1 << 40))
+        return PPO_E_BADARG;
+    if (!workspace || workspace_bytes < ppo_scan_ws_bytes(n_steps * n_envs)) return PPO_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)((n_envs + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    char* w = (char*)workspace;
+    w += align_up((size_t)(nb + 1) * sizeof(Aff), 256);
+    w += align_up((size_t)(nb + 1) * sizeof(double), 256);
+    Mom* mom = (Mom*)w;
+    scan_rows_kernel<<<nb, SCAN_BLOCK, 0, st>>>(rewards_tn, terminals_tn, n_steps, n_envs, gamma,
+                                                returns_tn, mom);
+    moments_finalize<<<1, 256, 0, st>>>(mom, nb, moments_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ppo_normalize_advantage(const float* returns, const float* old_values, int64_t n,
+                                       const double* moments, float* returns_norm,
+                                       float* advantages, void* stream) {
+    if (!returns || !old_values || !moments || !returns_norm || !advantages || n <= 0)
+        return PPO_E_BADARG;
+    const int64_t want = (n + 255) / 256;
+    const int grid = (int)(want < 2048 ? want : 2048);
+    normalize_adv_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(returns, old_values, n, moments,
+                                                               returns_norm, advantages);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,534 @@
+// K-epoch update: fused evaluate + clipped-surrogate loss + backward (one launch per epoch),
+// deterministic gradient reduction, two-learning-rate Adam.
+//
+// fwdbwd kernel: 256 workgroups of 4 waves, even workgroups train the actor, odd ones the critic
+// (the two MLPs share no parameters and their loss terms are independent given the precomputed
+// advantages, PPO.py:221,240).  A wave owns tiles of 32 samples and keeps, across all its tiles,
+// the weight-gradient accumulators of its MLP in MFMA accumulator registers:
+//   forward   Z^T[64, 32] = W[64, K] X^T[K, 32]      (activations stay in registers, sample on lane)
+//   dgrad     dH^T[64,32] = W^T[64,64] dZ^T[64,32]   (ditto)
+//   wgrad     dW[64, K]  += dZ^T[64,32] X[32, K]     (reduction over samples = over lanes: both
+//             operands are transposed through a per-wave LDS buffer with an odd row stride)
+// Bias gradients: layer 1 rides in the wgrad as a ones column of X; layer 2 is summed per lane and
+// reduced across lanes once at the end; the output layer's likewise.
+// Nothing is accumulated with atomics: per-wave -> per-workgroup (fixed wave order through LDS) ->
+// ppo_grad_reduce (fixed workgroup order), so results are bit-reproducible run to run.
+#include "ppo_common.h"
+
+#define FB_THREADS 256
+#define FB_WAVES 4
+#define FB_GRID 256  // one workgroup per CU; half per role
+
+struct FwdBwdArgs {
+    const float* params;
+    int S, A;
+    float action_var;
+    const float* states;
+    const void* actions;
+    const float* old_logp;
+    const float* adv;
+    const float* ret;
+    int64_t n;
+    float inv_n, clip_lo, clip_hi;
+    float* out_logp;
+    float* out_val;
+    float* out_ent;
+    float* out_surr;
+    float* partial_actor;   // [FB_GRID/2][stride_actor]
+    float* partial_critic;  // [FB_GRID/2][stride_critic]
+    int stride_actor, stride_critic;
+};
+
+__host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
+
+template <int HEAD, int AOUT, int JT>
+__device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
+    const int S = a.S;
+    const int A = HEAD == HEAD_VALUE ? 1 : a.A;
+    const NetLayout P = HEAD == HEAD_VALUE ? net_layout(n_actor_params(S, a.A), S, 1)
+                                           : net_layout(0, S, a.A);
+    const int base = HEAD == HEAD_VALUE ? n_actor_params(S, a.A) : 0;
+    const int wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+
+    const NetLds L = carve_net_lds(smem, S, AOUT, true);
+    float* stg = smem + round4(net_lds_floats(S, AOUT, true));
+    float* stgA = stg + wave * (2 * TILE_M * STG_LD);
+    float* stgB = stgA + TILE_M * STG_LD;
+    fill_net_lds(L, a.params, P, S, A, AOUT, true);
+    __syncthreads();
+
+    f32x16 gW2[2][2], gW1[2][JT], gW3[2], gb2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gW3[i] = 0.f;
+        gb2[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) gW2[i][j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) gW1[i][j] = 0.f;
+    }
+    float gb3[AOUT];
+#pragma unroll
+    for (int k = 0; k < AOUT; ++k) gb3[k] = 0.f;
+    double loss_acc = 0.0;
+
+    const int64_t n_tiles = (a.n + TILE_M - 1) / TILE_M;
+    for (int64_t tile = (int64_t)wg * FB_WAVES + wave; tile < n_tiles; tile += (int64_t)nwg * FB_WAVES) {
+        const int64_t m0 = tile * TILE_M;
+        const int64_t m = m0 + c;
+        const bool valid = m < a.n;
+
+        // ---------------- forward
+        f32x16 H1[2], H2[2];
+        mlp_fwd_tile(L, a.states, S, m, valid, c, h, H1, H2);
+        float o[AOUT];
+        out_layer<AOUT>(L, A, H2, h, o);
+
+        // ---------------- head, loss, gradient w.r.t. the pre-head outputs
+        float dout[AOUT];
+        if constexpr (HEAD == HEAD_VALUE) {
+            // 0.5 * MseLoss(state_values, rewards), PPO.py:240; d/dV of its mean = (V - R)/n
+            const float R = valid ? a.ret[m] : 0.f;
+            const float diff = o[0] - R;
+            dout[0] = valid ? diff * a.inv_n : 0.f;
+            if (valid && h == 0) {
+                loss_acc += (double)diff * (double)diff;
+                if (a.out_val) a.out_val[m] = o[0];
+            }
+        } else {
+            const float old_lp = valid ? a.old_logp[m] : 0.f;
+            const float adv = valid ? a.adv[m] : 0.f;
+            float logp, ent;
+            CatOut<AOUT> cat;
+            GaussOut<AOUT> gs;
+            int action = 0;
+            if constexpr (HEAD == HEAD_CATEGORICAL) {
+                action = valid ? reinterpret_cast<const int*>(a.actions)[m] : 0;
+                categorical_head<AOUT>(o, A, cat);
+                logp = cat.L[0];
+#pragma unroll
+                for (int k = 1; k < AOUT; ++k) logp = (k == action) ? cat.L[k] : logp;
+                ent = cat.ent;
+            } else {
+                float act[AOUT];
+                const float* ap = reinterpret_cast<const float*>(a.actions);
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) act[k] = (valid && k < A) ? ap[m * A + k] : 0.f;
+                gaussian_head<AOUT>(o, A, a.action_var, act, gs);
+                logp = gs.logp;
+                ent = gs.ent;
+            }
+            // PPO.py:233-240
+            const float ratio = expf(logp - old_lp);
+            const float s1 = ratio * adv;
+            const float s2 = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi) * adv;
+            const float surr = fminf(s1, s2);
+            // torch.min splits ties 1/2 + 1/2 and clamp passes gradient on the closed interval:
+            // inside the clip range the whole gradient flows through ratio; outside it only when
+            // the unclipped branch is the smaller one.
+            const bool inside = ratio >= a.clip_lo && ratio <= a.clip_hi;
+            const bool gate = inside || (adv >= 0.f ? ratio <= a.clip_hi : ratio >= a.clip_lo);
+            const float dlogp = (valid && gate) ? -(adv * ratio) * a.inv_n : 0.f;
+            const float dent = valid ? -0.01f * a.inv_n : 0.f;
+            if constexpr (HEAD == HEAD_CATEGORICAL) {
+                float pa = cat.pass[0], wq = 0.f;
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) {
+                    pa = (k == action) ? cat.pass[k] : pa;
+                    if (k < A) wq += (cat.L[k] + cat.pass[k]) * cat.q[k];
+                }
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) {
+                    const float onehot = (k == action) ? 1.f : 0.f;
+                    const float dz_logp = pa * (onehot - cat.q[k]);
+                    const float dz_ent = -(cat.q[k] * ((cat.L[k] + cat.pass[k]) - wq));
+                    dout[k] = k < A ? dlogp * dz_logp + dent * dz_ent : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k)
+                    dout[k] = k < A ? dlogp * (gs.zed[k] / gs.sigma) * (1.0f - gs.mu[k] * gs.mu[k]) : 0.f;
+            }
+            if (valid && h == 0) {
+                loss_acc += (double)(-surr - 0.01f * ent);
+                if (a.out_logp) a.out_logp[m] = logp;
+                if (a.out_ent) a.out_ent[m] = ent;
+                if (a.out_surr) a.out_surr[m] = surr;
+            }
+        }
+
+        // ---------------- output layer backward (VALU): dZ2 = (W3^T dout) * (1 - H2^2)
+        f32x16 dZ2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) {
+                    if (k < A) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[k * HID + 32 * t + 8 * q + 4 * h]);
+                        g0 = fmaf(w.x, dout[k], g0);
+                        g1 = fmaf(w.y, dout[k], g1);
+                        g2 = fmaf(w.z, dout[k], g2);
+                        g3 = fmaf(w.w, dout[k], g3);
+                    }
+                }
+                dZ2[t][4 * q + 0] = g0 * (1.0f - H2[t][4 * q + 0] * H2[t][4 * q + 0]);
+                dZ2[t][4 * q + 1] = g1 * (1.0f - H2[t][4 * q + 1] * H2[t][4 * q + 1]);
+                dZ2[t][4 * q + 2] = g2 * (1.0f - H2[t][4 * q + 2] * H2[t][4 * q + 2]);
+                dZ2[t][4 * q + 3] = g3 * (1.0f - H2[t][4 * q + 3] * H2[t][4 * q + 3]);
+            }
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) gb3[k] += dout[k];
+        }
+        gb2[0] += dZ2[0];
+        gb2[1] += dZ2[1];
+
+        // ---------------- wgrad of the output layer: dW3[a, u] += sum_m dout[m, a] H2[m, u]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
+        if (h == 0) {
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) stgA[c * STG_LD + k] = dout[k];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int mm = 2 * s + h;
+            const float av = c < AOUT ? stgA[mm * STG_LD + c] : 0.f;
+            const float b0 = stgB[mm * STG_LD + c];
+            const float b1 = stgB[mm * STG_LD + 32 + c];
+            gW3[0] = mfma32(av, b0, gW3[0]);
+            gW3[1] = mfma32(av, b1, gW3[1]);
+        }
+
+        // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                stgA[c * STG_LD + 32 * t + rho(r, h)] = dZ2[t][r];
+                stgB[c * STG_LD + 32 * t + rho(r, h)] = H1[t][r];
+            }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int mm = 2 * s + h;
+            const float a0 = stgA[mm * STG_LD + c];
+            const float a1 = stgA[mm * STG_LD + 32 + c];
+            const float b0 = stgB[mm * STG_LD + c];
+            const float b1 = stgB[mm * STG_LD + 32 + c];
+            gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
+            gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
+            gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
+            gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
+        }
+
+        // ---------------- dgrad of layer 2: dH1^T = W2^T dZ2^T, then through tanh
+        f32x16 dZ1[2];
+        dZ1[0] = 0.f;
+        dZ1[1] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * st + rho(r, h);  // output unit of layer 2
+                const float b = dZ2[st][r];
+                const float a0 = L.w2n[k * HID + c];
+                const float a1 = L.w2n[k * HID + 32 + c];
+                dZ1[0] = mfma32(a0, b, dZ1[0]);
+                dZ1[1] = mfma32(a1, b, dZ1[1]);
+            }
+        }
+        dZ1[0] = dZ1[0] * (1.0f - H1[0] * H1[0]);
+        dZ1[1] = dZ1[1] * (1.0f - H1[1] * H1[1]);
+
+        // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stgA[c * STG_LD + 32 * t + rho(r, h)] = dZ1[t][r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int mm = 2 * s + h;
+            const int64_t gm = m0 + mm;
+            const float a0 = stgA[mm * STG_LD + c];
+            const float a1 = stgA[mm * STG_LD + 32 + c];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const int in = 32 * jt + c;
+                float b = in == S ? 1.0f : 0.0f;
+                if (in < S && gm < a.n) b = a.states[gm * S + in];
+                gW1[0][jt] = mfma32(a0, b, gW1[0][jt]);
+                gW1[1][jt] = mfma32(a1, b, gW1[1][jt]);
+            }
+        }
+    }
+
+    // ---------------- reduce lanes -> wave -> workgroup -> global partial row
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = gb2[t][r];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            gb2[t][r] = v;
+        }
+#pragma unroll
+    for (int k = 0; k < AOUT; ++k) {
+        float v = gb3[k];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        gb3[k] = v;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) loss_acc += __shfl_xor(loss_acc, off);
+
+    __syncthreads();  // every wave is done with its staging buffers
+    float* red = stg;  // [P.n + 1], indices relative to this MLP's first parameter
+    const int o_w1 = P.w1 - base, o_b1 = P.b1 - base, o_w2 = P.w2 - base, o_b2 = P.b2 - base,
+              o_w3 = P.w3 - base, o_b3 = P.b3 - base, o_loss = P.n;
+    for (int w = 0; w < FB_WAVES; ++w) {
+        if (wave == w) {
+            const bool first = w == 0;
+#define RED_PUT(idx, val) { const int _i = (idx); red[_i] = first ? (val) : red[_i] + (val); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int out = 32 * i + rho(r, h);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) RED_PUT(o_w2 + out * HID + 32 * j + c, gW2[i][j][r]);
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const int in = 32 * jt + c;
+                        if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
+                        else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
+                    }
+                    if (c == 0) RED_PUT(o_b2 + out, gb2[i][r]);
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int act_row = rho(r, h);
+                    if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
+                }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
+                const float lv = HEAD == HEAD_VALUE ? (float)(0.5 * loss_acc * (double)a.inv_n)
+                                                    : (float)(loss_acc * (double)a.inv_n);
+                RED_PUT(o_loss, lv);
+            }
+#undef RED_PUT
+        }
+        __syncthreads();
+    }
+    float* dst = HEAD == HEAD_VALUE ? a.partial_critic + (size_t)wg * a.stride_critic
+                                    : a.partial_actor + (size_t)wg * a.stride_actor;
+    for (int i = threadIdx.x; i < P.n + 1; i += FB_THREADS) dst[i] = red[i];
+}
+
+template <bool CONT, int AMAX, int JT>
+__global__ __launch_bounds__(FB_THREADS, 1) void fwdbwd_kernel(const FwdBwdArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    if ((blockIdx.x & 1) == 0)
+        run_role<CONT ? HEAD_GAUSSIAN : HEAD_CATEGORICAL, AMAX, JT>(a, smem);
+    else
+        run_role<HEAD_VALUE, 1, JT>(a, smem);
+}
+
+// grad[p] = sum over the role's workgroups (fixed order, fp64 accumulate).
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial_actor,
+                                                          const float* __restrict__ partial_critic,
+                                                          int stride_actor, int stride_critic,
+                                                          int n_actor, int n_critic, int rows,
+                                                          float* __restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = n_actor + n_critic;
+    if (i >= P + 2) return;
+    const float* src;
+    int stride;
+    if (i < n_actor) { src = partial_actor + i; stride = stride_actor; }
+    else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; }
+    else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; }
+    else { src = partial_critic + n_critic; stride = stride_critic; }
+    double s = 0.0;
+    for (int g = 0; g < rows; ++g) s += (double)src[(size_t)g * stride];
+    grad[i] = (float)s;
+}
+
+// torch/optim/adam.py:457-547, single-tensor path; operation order kept (no contraction).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ params,
+                                                   const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   int n, int n_actor, float neg_step_actor,
+                                                   float neg_step_critic, float one_minus_b1,
+                                                   float b2, float one_minus_b2, float bc2_sqrt,
+                                                   float eps, float* __restrict__ loss_out) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && loss_out) loss_out[0] = grad[n] + grad[n + 1];
+    if (i >= n) return;
+    const float g = grad[i];
+    float mi = m[i], vi = v[i];
+    mi = mi + one_minus_b1 * (g - mi);          // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * b2;                               // exp_avg_sq.mul_(beta2)
+    vi = vi + (one_minus_b2 * g) * g;           //   .addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float ns = i < n_actor ? neg_step_actor : neg_step_critic;
+    params[i] = params[i] + (ns * mi) / denom;  // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m[i] = mi;
+    v[i] = vi;
+}
+
+// ---------------------------------------------------------------------------- host side
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+size_t ppo_scan_ws_bytes(int64_t n);  // scan.hip
+
+static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
+
+static size_t update_ws_bytes(int S, int A) {
+    const size_t rows = FB_GRID / 2;
+    return align_up(rows * stride_of(n_actor_params(S, A)) * sizeof(float), 256) +
+           align_up(rows * stride_of(n_critic_params(S)) * sizeof(float), 256);
+}
+
+extern "C" size_t ppo_workspace_bytes(int state_dim, int action_dim, int64_t max_samples) {
+    if (state_dim < 1 || action_dim < 1 || max_samples < 1) return 0;
+    const size_t a = update_ws_bytes(state_dim, action_dim);
+    const size_t b = ppo_scan_ws_bytes(max_samples);
+    return a > b ? a : b;
+}
+
+extern "C" int64_t ppo_param_count(int state_dim, int action_dim, int64_t* n_actor_out) {
+    const int na = n_actor_params(state_dim, action_dim);
+    if (n_actor_out) *n_actor_out = na;
+    return (int64_t)na + n_critic_params(state_dim);
+}
+
+static size_t fwdbwd_lds_bytes(int S, int amax) {
+    const int net = round4(net_lds_floats(S, amax, true));
+    return (size_t)(net + FB_WAVES * 2 * TILE_M * STG_LD) * sizeof(float);
+}
+
+template <bool CONT, int AMAX, int JT>
+static int launch_fwdbwd(const FwdBwdArgs& a, hipStream_t st) {
+    const size_t lds = fwdbwd_lds_bytes(a.S, AMAX);
+    static size_t configured = 0;
+    if (lds > configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)fwdbwd_kernel<CONT, AMAX, JT>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        configured = lds;
+    }
+    fwdbwd_kernel<CONT, AMAX, JT><<<FB_GRID, FB_THREADS, lds, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_dim, int continuous,
+                                float action_var, const float* states, const void* actions,
+                                const float* old_logprobs, const float* advantages,
+                                const float* returns_norm, int64_t n_local, int64_t n_global,
+                                float eps_clip, float* out_logprobs, float* out_values,
+                                float* out_entropy, float* out_surrogate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (!params || !states || !actions || !old_logprobs || !advantages || !returns_norm ||
+        n_local <= 0 || n_global < n_local)
+        return PPO_E_BADARG;
+    if (state_dim < 1 || state_dim > PPO_MAX_STATE_DIM || action_dim < 1 ||
+        action_dim > PPO_MAX_ACTION_DIM)
+        return PPO_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
+    FwdBwdArgs a;
+    a.params = params;
+    a.S = state_dim;
+    a.A = action_dim;
+    a.action_var = action_var;
+    a.states = states;
+    a.actions = actions;
+    a.old_logp = old_logprobs;
+    a.adv = advantages;
+    a.ret = returns_norm;
+    a.n = n_local;
+    a.inv_n = 1.0f / (float)n_global;
+    // 1-eps_clip and 1+eps_clip are Python doubles handed to clamp on an fp32 tensor (PPO.py:237)
+    a.clip_lo = (float)(1.0 - (double)eps_clip);
+    a.clip_hi = (float)(1.0 + (double)eps_clip);
+    a.out_logp = out_logprobs;
+    a.out_val = out_values;
+    a.out_ent = out_entropy;
+    a.out_surr = out_surrogate;
+    a.stride_actor = stride_of(n_actor_params(state_dim, action_dim));
+    a.stride_critic = stride_of(n_critic_params(state_dim));
+    a.partial_actor = (float*)workspace;
+    a.partial_critic = (float*)((char*)workspace +
+                                align_up((size_t)(FB_GRID / 2) * a.stride_actor * sizeof(float), 256));
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = state_dim + 1 > 32;
+    const bool a8 = action_dim > 4;
+    if (continuous) {
+        if (!wide) return a8 ? launch_fwdbwd<true, 8, 1>(a, st) : launch_fwdbwd<true, 4, 1>(a, st);
+        return a8 ? launch_fwdbwd<true, 8, 2>(a, st) : launch_fwdbwd<true, 4, 2>(a, st);
+    }
+    if (!wide) return a8 ? launch_fwdbwd<false, 8, 1>(a, st) : launch_fwdbwd<false, 4, 1>(a, st);
+    return a8 ? launch_fwdbwd<false, 8, 2>(a, st) : launch_fwdbwd<false, 4, 2>(a, st);
+}
+
+extern "C" int ppo_grad_reduce(int state_dim, int action_dim, const void* workspace,
+                               size_t workspace_bytes, float* grad_out, void* stream) {
+    if (!workspace || !grad_out) return PPO_E_BADARG;
+    if (state_dim < 1 || state_dim > PPO_MAX_STATE_DIM || action_dim < 1 ||
+        action_dim > PPO_MAX_ACTION_DIM)
+        return PPO_E_UNSUPPORTED;
+    if (workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
+    const int na = n_actor_params(state_dim, action_dim), nc = n_critic_params(state_dim);
+    const int sa = stride_of(na), sc = stride_of(nc);
+    const float* pa = (const float*)workspace;
+    const float* pc = (const float*)((const char*)workspace +
+                                     align_up((size_t)(FB_GRID / 2) * sa * sizeof(float), 256));
+    const int total = na + nc + 2;
+    grad_reduce_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(pa, pc, sa, sc, na, nc,
+                                                                            FB_GRID / 2, grad_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ppo_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             int64_t n_params, int64_t n_actor, int64_t step, double lr_actor,
+                             double lr_critic, double beta1, double beta2, double eps,
+                             float* loss_out, void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq || n_params <= 0 || n_actor < 0 ||
+        n_actor > n_params || step < 1 || n_params > (1 << 30))
+        return PPO_E_BADARG;
+    // bias corrections in double, as the reference's Python floats (adam.py:531-536)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float nsa = (float)(-(lr_actor / bc1));
+    const float nsc = (float)(-(lr_critic / bc1));
+    adam_kernel<<<(int)((n_params + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        params, grad, exp_avg, exp_avg_sq, (int)n_params, (int)n_actor, nsa, nsc,
+        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, loss_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ppo_hip_abi_version(void) { return 1; }
+
+extern "C" const char* ppo_hip_strerror(int code) {
+    switch (code) {
+        case 0: return "success";
+        case PPO_E_BADARG: return "ppo_hip: bad argument (null pointer, non-positive size or inconsistent shape)";
+        case PPO_E_WORKSPACE: return "ppo_hip: workspace missing or smaller than ppo_workspace_bytes()";
+        case PPO_E_UNSUPPORTED: return "ppo_hip: state_dim or action_dim beyond PPO_MAX_STATE_DIM / PPO_MAX_ACTION_DIM";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ppo_hip: unknown error";
+    }
+}

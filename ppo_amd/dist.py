@@ -1,0 +1,48 @@
+"""Data parallelism over envs/samples: one process per GPU, torch.distributed (backend "nccl" is
+RCCL on ROCm; "gloo" on CPU for the tests).
+
+The reference has no distributed code at all (single process, README.md:23); what must hold is
+that W shards reproduce the single-buffer update of PPO.py:200-251:
+  * PPO.py:212 normalises over the WHOLE buffer -> the per-shard (count, mean, M2) triples are
+    all-gathered and merged in rank order (identical result on every rank);
+  * PPO.py:244 differentiates the mean over ALL samples -> every shard scales its gradient by
+    1/n_global and the P+2 floats (gradient + the two loss terms) are summed with one all-reduce
+    per epoch.  The message is ~37-49 KB, i.e. latency-bound: one collective per epoch, no buckets.
+Parameters and Adam state are replicated and stay bit-identical because every rank applies the
+same all-reduced gradient.
+"""
+import torch
+import torch.distributed as td
+
+
+def is_distributed():
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def merge_moments_list(triples):
+    """Chan et al. pairwise merge of (count, mean, M2) rows [W, 3] in row order (fp64)."""
+    n, mean, m2 = triples[0, 0], triples[0, 1], triples[0, 2]
+    for i in range(1, triples.shape[0]):
+        nb, mb, m2b = triples[i, 0], triples[i, 1], triples[i, 2]
+        tot = n + nb
+        delta = mb - mean
+        mean = mean + delta * (nb / tot)
+        m2 = m2 + m2b + delta * delta * (n * nb / tot)
+        n = tot
+    return torch.stack([n, mean, m2])
+
+
+def merge_moments(moments):
+    """moments: fp64 [3] on this rank -> merged over all ranks (same tensor if not distributed)."""
+    if not is_distributed():
+        return moments
+    world = td.get_world_size()
+    gathered = torch.empty(world * 3, dtype=moments.dtype, device=moments.device)
+    td.all_gather_into_tensor(gathered, moments.contiguous())
+    return merge_moments_list(gathered.view(world, 3)).contiguous()
+
+
+def all_reduce_sum(t):
+    if is_distributed():
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t

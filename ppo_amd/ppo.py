@@ -1,0 +1,608 @@
+"""Host-side mirror of the reference's PPO.py class surface, backed by the gfx950 HIP engine.
+
+Same names, argument order and observable behaviour as the reference module
+(/root/reference/PPO.py): module-level ``device``, ``RolloutBuffer``, ``ActorCritic``, ``PPO`` with
+``select_action`` / ``update`` / ``set_action_std`` / ``decay_action_std`` / ``save`` / ``load``.
+All arithmetic runs in libppo_hip.so through the C ABI of include/ppo_hip.h; PyTorch owns the
+device memory and the streams, nothing else.  There is no CPU fallback: without a GPU the objects
+can be constructed and (de)serialised, and every compute call raises.
+
+Beyond the reference surface (which handles one env step per call) the same objects accept a
+batch of N lockstep envs per call: ``select_action(states[N, S])`` and tensor-valued
+``buffer.rewards.append(r[N])`` / ``buffer.is_terminals.append(done[N])``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import dist as _dist
+
+################################## set device ##################################
+print("============================================================================================")
+# set device to cpu or cuda  (PPO.py:6-16)
+device = torch.device('cpu')
+if torch.cuda.is_available():
+    device = torch.device('cuda:0')
+    torch.cuda.empty_cache()
+    print("Device set to : " + str(torch.cuda.get_device_name(device)))
+else:
+    print("Device set to : cpu")
+print("============================================================================================")
+
+HIDDEN = 64
+
+
+def _require_gpu():
+    if device.type != 'cuda':
+        raise RuntimeError("ppo_amd: no GPU visible; the HIP engine has no CPU fallback")
+
+
+def _param_layout(state_dim, action_dim):
+    """(key, shape) in state_dict order of the reference's ActorCritic (PPO.py:49-73)."""
+    out = []
+    for pre, o in (("actor", action_dim), ("critic", 1)):
+        out += [(f"{pre}.0.weight", (HIDDEN, state_dim)), (f"{pre}.0.bias", (HIDDEN,)),
+                (f"{pre}.2.weight", (HIDDEN, HIDDEN)), (f"{pre}.2.bias", (HIDDEN,)),
+                (f"{pre}.4.weight", (o, HIDDEN)), (f"{pre}.4.bias", (o,))]
+    return out
+
+
+################################## PPO Policy ##################################
+class _Column:
+    """List-like view of one per-step column of the device-resident rollout buffer.
+
+    Supports what callers of the reference do with ``buffer.<name>``: ``len``, indexing,
+    iteration, ``append`` and ``del col[:]`` (RolloutBuffer.clear, PPO.py:29-35).
+    """
+
+    def __init__(self, buf, name):
+        self._buf = buf
+        self._name = name
+
+    def __len__(self):
+        return self._buf._count[self._name]
+
+    def __getitem__(self, i):
+        n = len(self)
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(n))]
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("list index out of range")
+        return self._buf._element(self._name, i)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def append(self, value):
+        self._buf._append(self._name, value)
+
+    def __delitem__(self, key):
+        if not (isinstance(key, slice) and key.indices(len(self)) == (0, len(self), 1)):
+            raise NotImplementedError("only `del column[:]` is supported on a device column")
+        self._buf._count[self._name] = 0
+
+    def __repr__(self):
+        return f"<device column {self._name}: {len(self)} steps>"
+
+
+class _HostColumn(list):
+    """``buffer.rewards`` / ``buffer.is_terminals``: a plain Python list for scalar appends
+    (train.py:180-181); a tensor/array of N values is one lockstep step of N envs and goes straight
+    to the device buffer."""
+
+    def __init__(self, buf, name):
+        super().__init__()
+        self._buf = buf
+        self._name = name
+
+    def append(self, value):
+        if isinstance(value, (torch.Tensor, np.ndarray)) and getattr(value, "ndim", 0) >= 1 \
+                and value.shape[0] > 1:
+            self._buf._append_step(self._name, value)
+        else:
+            if isinstance(value, (torch.Tensor, np.ndarray)):
+                value = value.reshape(-1)[0].item()
+            super().append(value)
+
+    def __len__(self):
+        return super().__len__() + self._buf._count[self._name]
+
+    def __delitem__(self, key):
+        super().__delitem__(key)
+        if isinstance(key, slice):
+            self._buf._count[self._name] = 0
+
+
+class RolloutBuffer:
+    """Device-resident structure-of-arrays rollout buffer with the reference's list facade.
+
+    Storage (grown geometrically, fp32 unless noted): states [cap, S], actions int32 [cap] or
+    [cap, A], logprobs [cap], state_values [cap], returns/advantages scratch; in batched mode also
+    rewards [cap] and terminals uint8 [cap].  Rows are in append order; a batched step of N envs
+    occupies N consecutive rows (time-major [steps, N]).
+    """
+
+    def __init__(self, state_dim=None, action_dim=None, continuous=False, dev=None):
+        self._S, self._A, self._cont = state_dim, action_dim, continuous
+        self._dev = dev if dev is not None else device
+        self._cap = 0
+        self._count = {"actions": 0, "states": 0, "logprobs": 0, "state_values": 0,
+                       "rewards": 0, "is_terminals": 0}
+        self._n_envs = 1
+        self._store = {}
+        self.actions = _Column(self, "actions")
+        self.states = _Column(self, "states")
+        self.logprobs = _Column(self, "logprobs")
+        self.rewards = _HostColumn(self, "rewards")
+        self.state_values = _Column(self, "state_values")
+        self.is_terminals = _HostColumn(self, "is_terminals")
+
+    # ---- storage
+    def _shapes(self):
+        S, A = self._S, self._A
+        return {"states": ((S,), torch.float32),
+                "actions": ((A,), torch.float32) if self._cont else ((), torch.int32),
+                "logprobs": ((), torch.float32), "state_values": ((), torch.float32),
+                "rewards": ((), torch.float32), "is_terminals": ((), torch.uint8),
+                "returns": ((), torch.float32), "advantages": ((), torch.float32)}
+
+    def reserve(self, rows):
+        if rows <= self._cap:
+            return
+        cap = max(rows, 2 * self._cap, 1024)
+        for name, (shp, dt) in self._shapes().items():
+            new = torch.empty((cap,) + shp, dtype=dt, device=self._dev)
+            old = self._store.get(name)
+            if old is not None and self._cap:
+                new[:self._cap] = old
+            self._store[name] = new
+        self._cap = cap
+
+    def rows(self, name, lo, hi):
+        return self._store[name][lo:hi]
+
+    @property
+    def n_envs(self):
+        return self._n_envs
+
+    # ---- list facade
+    def _element(self, name, i):
+        t = self._store[name][i]
+        if name == "actions":
+            return t.reshape(1, self._A) if self._cont else t.to(torch.int64)
+        if name == "logprobs":
+            return t.reshape(1) if self._cont else t
+        if name == "state_values":
+            return t.reshape(1)
+        return t
+
+    def _append(self, name, value):
+        i = self._count[name]
+        self.reserve(i + 1)
+        dst = self._store[name]
+        v = torch.as_tensor(value, device=self._dev)
+        dst[i] = v.reshape(dst[i].shape).to(dst.dtype)
+        self._count[name] = i + 1
+
+    def _append_step(self, name, value):
+        v = torch.as_tensor(value, device=self._dev).reshape(-1)
+        n = v.shape[0]
+        i = self._count[name]
+        self.reserve(i + n)
+        dst = self._store[name]
+        dst[i:i + n] = v.to(dst.dtype) if name != "is_terminals" else (v != 0).to(torch.uint8)
+        self._count[name] = i + n
+        self._n_envs = n
+
+    def claim_step(self, n):
+        """Rows [lo, lo+n) for the next lockstep step: the four act() columns advance together."""
+        lo = self._count["states"]
+        self.reserve(lo + n)
+        for k in ("states", "actions", "logprobs", "state_values"):
+            self._count[k] = lo + n
+        if n > 1:
+            self._n_envs = n
+        return lo
+
+    def claim_env_slots(self, n):
+        """In-place variant for device-side envs: views of the next step's reward/terminal rows
+        (the env kernel writes them; counts advance here)."""
+        lo = self._count["rewards"]
+        self.reserve(lo + n)
+        self._count["rewards"] = lo + n
+        self._count["is_terminals"] = lo + n
+        self._n_envs = n
+        return self._store["rewards"][lo:lo + n], self._store["is_terminals"][lo:lo + n]
+
+    def load_rollout(self, states, actions, logprobs, state_values, rewards, is_terminals):
+        """Replay: replace the buffer content with one recorded flat rollout (arrays of T steps in
+        the reference's append order).  rewards / is_terminals stay host lists of Python scalars,
+        exactly what train.py:180-181 would have appended."""
+        self.clear()
+        T = len(rewards)
+        self.reserve(T)
+        put = lambda name, arr, dt: self._store[name][:T].copy_(
+            torch.as_tensor(np.asarray(arr), dtype=dt).reshape(self._store[name][:T].shape))
+        put("states", states, torch.float32)
+        put("actions", actions, torch.float32 if self._cont else torch.int32)
+        put("logprobs", logprobs, torch.float32)
+        put("state_values", state_values, torch.float32)
+        for k in ("states", "actions", "logprobs", "state_values"):
+            self._count[k] = T
+        list.extend(self.rewards, [float(r) for r in rewards])
+        list.extend(self.is_terminals, [bool(t) for t in is_terminals])
+
+    def clear(self):
+        """PPO.py:29-35."""
+        del self.actions[:]
+        del self.states[:]
+        del self.logprobs[:]
+        del self.rewards[:]
+        del self.state_values[:]
+        del self.is_terminals[:]
+        self._n_envs = 1
+
+
+class ActorCritic(nn.Module):
+    """Parameter holder with the reference's module tree (PPO.py:38-73): ``actor`` and ``critic``
+    are nn.Sequential stacks whose weights are VIEWS into one flat fp32 device vector laid out in
+    state_dict order - the vector the HIP kernels read and the fused Adam writes."""
+
+    def __init__(self, state_dim, action_dim, has_continuous_action_space, action_std_init):
+        super(ActorCritic, self).__init__()
+        self.has_continuous_action_space = has_continuous_action_space
+        self.state_dim = state_dim
+        self.action_dim = action_dim
+        if has_continuous_action_space:
+            self.action_var = torch.full((action_dim,), action_std_init * action_std_init).to(device)
+        # same construction order as the reference so default init draws match under a seed
+        head = nn.Tanh() if has_continuous_action_space else nn.Softmax(dim=-1)
+        self.actor = nn.Sequential(nn.Linear(state_dim, 64), nn.Tanh(), nn.Linear(64, 64),
+                                   nn.Tanh(), nn.Linear(64, action_dim), head)
+        self.critic = nn.Sequential(nn.Linear(state_dim, 64), nn.Tanh(), nn.Linear(64, 64),
+                                    nn.Tanh(), nn.Linear(64, 1))
+        self._flatten()
+
+    def _flatten(self):
+        n_actor = ctypes.c_int64()
+        total = _lib.lib().ppo_param_count(self.state_dim, self.action_dim, ctypes.byref(n_actor))
+        self.n_actor = int(n_actor.value)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        off = 0
+        sd = dict(self.named_parameters())
+        for key, shp in _param_layout(self.state_dim, self.action_dim):
+            p = sd[key]
+            n = p.numel()
+            view = flat[off:off + n].view(shp)
+            view.copy_(p.data)
+            p.data = view
+            p.requires_grad_(False)
+            off += n
+        assert off == total
+        self.flat = flat
+
+    def _apply(self, fn, recurse=True):
+        # .to(device) must not re-allocate the tensors and break the views
+        return self
+
+    def set_action_std(self, new_action_std):
+        if self.has_continuous_action_space:
+            self.action_var = torch.full((self.action_dim,), new_action_std * new_action_std).to(device)
+        else:
+            print("--------------------------------------------------------------------------------------------")
+            print("WARNING : Calling ActorCritic::set_action_std() on discrete action space policy")
+            print("--------------------------------------------------------------------------------------------")
+
+    def forward(self):
+        raise NotImplementedError
+
+    def _var32(self):
+        return float(self.action_var[0].item()) if self.has_continuous_action_space else 0.0
+
+    def act(self, state, _seed=None, _offset=0, _out=None):
+        """Batched ActorCritic.act (PPO.py:86-100): state [S] or [N, S] -> (action, logprob, value)."""
+        _require_gpu()
+        x = torch.as_tensor(state, dtype=torch.float32, device=device)
+        single = x.dim() == 1
+        x = x.reshape(-1, self.state_dim).contiguous()
+        n = x.shape[0]
+        if _out is None:
+            act = (torch.empty((n, self.action_dim), dtype=torch.float32, device=device)
+                   if self.has_continuous_action_space
+                   else torch.empty((n,), dtype=torch.int32, device=device))
+            logp = torch.empty((n,), dtype=torch.float32, device=device)
+            val = torch.empty((n,), dtype=torch.float32, device=device)
+        else:
+            act, logp, val = _out
+        if _seed is None:
+            _seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        _lib.check(_lib.lib().ppo_act(self.flat.data_ptr(), self.state_dim, self.action_dim,
+                                      int(self.has_continuous_action_space), self._var32(),
+                                      x.data_ptr(), n, _seed, _offset, act.data_ptr(),
+                                      logp.data_ptr(), val.data_ptr(), _lib.stream_ptr()))
+        if _out is not None:
+            return act, logp, val
+        if self.has_continuous_action_space:
+            return (act.reshape(1, -1), logp.reshape(1), val.reshape(1)) if single else (act, logp, val.reshape(-1, 1))
+        if single:
+            return act.to(torch.int64).reshape(()), logp.reshape(()), val.reshape(1)
+        return act.to(torch.int64), logp, val.reshape(-1, 1)
+
+    def evaluate(self, state, action):
+        """ActorCritic.evaluate forward (PPO.py:102-121) -> (logprobs [T], values [T,1], entropy [T]).
+        Plain tensors: the backward pass lives in the fused update kernel, not in autograd."""
+        _require_gpu()
+        x = torch.as_tensor(state, dtype=torch.float32, device=device).reshape(-1, self.state_dim).contiguous()
+        n = x.shape[0]
+        if self.has_continuous_action_space:
+            a = torch.as_tensor(action, dtype=torch.float32, device=device).reshape(n, self.action_dim).contiguous()
+        else:
+            a = torch.as_tensor(action, device=device).reshape(n).to(torch.int32).contiguous()
+        logp = torch.empty((n,), dtype=torch.float32, device=device)
+        val = torch.empty((n,), dtype=torch.float32, device=device)
+        ent = torch.empty((n,), dtype=torch.float32, device=device)
+        _lib.check(_lib.lib().ppo_evaluate(self.flat.data_ptr(), self.state_dim, self.action_dim,
+                                           int(self.has_continuous_action_space), self._var32(),
+                                           x.data_ptr(), a.data_ptr(), n, logp.data_ptr(),
+                                           val.data_ptr(), ent.data_ptr(), _lib.stream_ptr()))
+        return logp, val.reshape(-1, 1), ent
+
+
+class FusedAdam:
+    """Adam state for the flat parameter vector with the two learning-rate groups of PPO.py:139-142.
+    Keeps torch.optim's visible shape (``param_groups``, ``state_dict``, ``zero_grad``, ``step``)."""
+
+    def __init__(self, policy, lr_actor, lr_critic, betas=(0.9, 0.999), eps=1e-8):
+        self.policy = policy
+        self.param_groups = [{'params': list(policy.actor.parameters()), 'lr': lr_actor,
+                              'betas': betas, 'eps': eps},
+                             {'params': list(policy.critic.parameters()), 'lr': lr_critic,
+                              'betas': betas, 'eps': eps}]
+        n = policy.flat.numel()
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n + 2, dtype=torch.float32, device=device)  # [P]=surrogate, [P+1]=value loss
+        self.step_count = 0
+
+    def zero_grad(self):
+        pass  # the reduction kernel overwrites the gradient every epoch
+
+    def step(self, loss_out=None):
+        _require_gpu()
+        self.step_count += 1
+        g0, g1 = self.param_groups
+        _lib.check(_lib.lib().ppo_adam_step(
+            self.policy.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+            self.exp_avg_sq.data_ptr(), self.policy.flat.numel(), self.policy.n_actor,
+            self.step_count, g0['lr'], g1['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
+            _lib.ptr(loss_out), _lib.stream_ptr()))
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg.cpu(), 'exp_avg_sq': self.exp_avg_sq.cpu(),
+                'lr': [g['lr'] for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        for g, lr in zip(self.param_groups, sd['lr']):
+            g['lr'] = lr
+
+
+class PPO:
+    def __init__(self, state_dim, action_dim, lr_actor, lr_critic, gamma, K_epochs, eps_clip,
+                 has_continuous_action_space, action_std_init=0.6):
+
+        self.has_continuous_action_space = has_continuous_action_space
+
+        if has_continuous_action_space:
+            self.action_std = action_std_init
+
+        self.gamma = gamma
+        self.eps_clip = eps_clip
+        self.K_epochs = K_epochs
+        self.state_dim = state_dim
+        self.action_dim = action_dim
+
+        self.buffer = RolloutBuffer(state_dim, action_dim, has_continuous_action_space)
+
+        self.policy = ActorCritic(state_dim, action_dim, has_continuous_action_space, action_std_init).to(device)
+        self.optimizer = FusedAdam(self.policy, lr_actor, lr_critic)
+
+        self.policy_old = ActorCritic(state_dim, action_dim, has_continuous_action_space, action_std_init).to(device)
+        self.policy_old.load_state_dict(self.policy.state_dict())
+
+        self.MseLoss = nn.MSELoss()
+
+        # engine state
+        self._rng_seed = None      # drawn from torch's generator on first use (honours torch.manual_seed)
+        self._rng_offset = 0
+        self._ws = None
+        self._moments = torch.zeros(3, dtype=torch.float64, device=device)
+        self.kernel_events = None  # set to a list to collect (start, end) CUDA events around every fwd/bwd launch
+        self.last_loss = None      # device tensor [K_epochs]: loss.mean() of every epoch of the last update
+        self.debug_outputs = None  # optional dict of per-sample first-epoch outputs (set by update(debug=True))
+
+    # ------------------------------------------------------------------ std schedule (PPO.py:149-173)
+    def set_action_std(self, new_action_std):
+        if self.has_continuous_action_space:
+            self.action_std = new_action_std
+            self.policy.set_action_std(new_action_std)
+            self.policy_old.set_action_std(new_action_std)
+        else:
+            print("--------------------------------------------------------------------------------------------")
+            print("WARNING : Calling PPO::set_action_std() on discrete action space policy")
+            print("--------------------------------------------------------------------------------------------")
+
+    def decay_action_std(self, action_std_decay_rate, min_action_std):
+        print("--------------------------------------------------------------------------------------------")
+        if self.has_continuous_action_space:
+            self.action_std = self.action_std - action_std_decay_rate
+            self.action_std = round(self.action_std, 4)
+            if (self.action_std <= min_action_std):
+                self.action_std = min_action_std
+                print("setting actor output action_std to min_action_std : ", self.action_std)
+            else:
+                print("setting actor output action_std to : ", self.action_std)
+            self.set_action_std(self.action_std)
+
+        else:
+            print("WARNING : Calling PPO::decay_action_std() on discrete action space policy")
+        print("--------------------------------------------------------------------------------------------")
+
+    # ------------------------------------------------------------------ rollout (PPO.py:175-198)
+    def _next_rng(self):
+        if self._rng_seed is None:
+            self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._rng_offset += 1
+        return self._rng_seed, self._rng_offset
+
+    def select_action(self, state):
+        """One env: ``state`` of shape [S] -> int (discrete) or np.ndarray[A] float32 (continuous),
+        exactly as the reference.  N lockstep envs: ``state`` of shape [N, S] (ndarray or tensor)
+        -> device tensor of N actions (int64 [N] or float32 [N, A]); nothing is copied to the host."""
+        _require_gpu()
+        x = torch.as_tensor(state, dtype=torch.float32, device=device) \
+            if not (isinstance(state, torch.Tensor) and state.dtype == torch.float32 and state.device == device) \
+            else state
+        batched = x.dim() == 2
+        x = x.reshape(-1, self.state_dim)
+        n = x.shape[0]
+        b = self.buffer
+        lo = b.claim_step(n)
+        b.rows("states", lo, lo + n).copy_(x)
+        self._act_rows(lo, n)
+        act = b.rows("actions", lo, lo + n)
+        if batched:
+            return act if self.has_continuous_action_space else act.to(torch.int64)
+        if self.has_continuous_action_space:
+            return act.detach().cpu().numpy().flatten()
+        return int(act.item())
+
+    def act_inplace(self, n_envs):
+        """Device-side env variant: the env has already written this step's states into
+        ``buffer.rows('states', lo, lo+n)`` obtained from ``next_state_slot``; acts on them in place
+        and returns the device view of the N actions."""
+        lo = self._pending_lo
+        self._act_rows(lo, n_envs)
+        return self.buffer.rows("actions", lo, lo + n_envs)
+
+    def next_state_slot(self, n_envs):
+        lo = self.buffer.claim_step(n_envs)
+        self._pending_lo = lo
+        return self.buffer.rows("states", lo, lo + n_envs)
+
+    def _act_rows(self, lo, n):
+        b = self.buffer
+        seed, off = self._next_rng()
+        self.policy_old.act(b.rows("states", lo, lo + n), _seed=seed, _offset=off,
+                            _out=(b.rows("actions", lo, lo + n), b.rows("logprobs", lo, lo + n),
+                                  b.rows("state_values", lo, lo + n)))
+
+    # ------------------------------------------------------------------ update (PPO.py:200-251)
+    def _workspace(self, n):
+        need = _lib.lib().ppo_workspace_bytes(self.state_dim, self.action_dim, n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def update(self, debug=False):
+        _require_gpu()
+        L = _lib.lib()
+        b = self.buffer
+        st = _lib.stream_ptr()
+        T = b._count["states"]
+        host_rewards = list.__len__(b.rewards)
+        dev_rewards = b._count["rewards"]
+        if T == 0 or (host_rewards + dev_rewards) != T or \
+                (list.__len__(b.is_terminals) + b._count["is_terminals"]) != T:
+            raise RuntimeError(f"rollout buffer is inconsistent: {T} acted steps, "
+                               f"{host_rewards + dev_rewards} rewards, "
+                               f"{list.__len__(b.is_terminals) + b._count['is_terminals']} terminal flags")
+        ws = self._workspace(T)
+        returns = b.rows("returns", 0, T)
+        adv = b.rows("advantages", 0, T)
+
+        # Monte Carlo estimate of returns (PPO.py:202-211)
+        if host_rewards:
+            if dev_rewards:
+                raise RuntimeError("mixing scalar and batched reward appends in one rollout is not supported")
+            # Python floats are doubles: keep them as fp64 so the scan sees what the reference sees
+            r64 = torch.tensor(list(b.rewards), dtype=torch.float64).to(device, non_blocking=True)
+            term = torch.tensor([bool(x) for x in list(b.is_terminals)], dtype=torch.uint8).to(device, non_blocking=True)
+            _lib.check(L.ppo_returns_scan_flat(r64.data_ptr(), 1, term.data_ptr(), T, float(self.gamma),
+                                               returns.data_ptr(), self._moments.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), st))
+        else:
+            n_envs = b.n_envs
+            if T % n_envs:
+                raise RuntimeError(f"batched rollout of {T} samples is not a multiple of {n_envs} envs")
+            _lib.check(L.ppo_returns_scan_rows(b.rows("rewards", 0, T).data_ptr(),
+                                               b.rows("is_terminals", 0, T).data_ptr(), T // n_envs, n_envs,
+                                               float(self.gamma), returns.data_ptr(),
+                                               self._moments.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        # Normalizing the rewards (PPO.py:212) over ALL data-parallel shards, advantages (PPO.py:221)
+        moments = _dist.merge_moments(self._moments)
+        T_global = T if not _dist.is_distributed() else int(round(float(moments[0].item())))
+        _lib.check(L.ppo_normalize_advantage(returns.data_ptr(), b.rows("state_values", 0, T).data_ptr(), T,
+                                             moments.data_ptr(), returns.data_ptr(), adv.data_ptr(), st))
+
+        # Optimize policy for K epochs (PPO.py:224-245)
+        pol, opt = self.policy, self.optimizer
+        P = pol.flat.numel()
+        losses = torch.empty(self.K_epochs, dtype=torch.float32, device=device)
+        dbg = None
+        if debug:
+            dbg = {k: torch.empty(T, dtype=torch.float32, device=device)
+                   for k in ("logprobs", "state_values", "entropy", "surrogate")}
+        var32 = pol._var32()
+        for e in range(self.K_epochs):
+            d = dbg if (dbg is not None and e == 0) else None
+            if self.kernel_events is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            _lib.check(L.ppo_epoch_fwdbwd(
+                pol.flat.data_ptr(), self.state_dim, self.action_dim, int(self.has_continuous_action_space),
+                var32, b.rows("states", 0, T).data_ptr(), b.rows("actions", 0, T).data_ptr(),
+                b.rows("logprobs", 0, T).data_ptr(), adv.data_ptr(), returns.data_ptr(), T, T_global,
+                float(self.eps_clip),
+                _lib.ptr(d["logprobs"]) if d else None, _lib.ptr(d["state_values"]) if d else None,
+                _lib.ptr(d["entropy"]) if d else None, _lib.ptr(d["surrogate"]) if d else None,
+                ws.data_ptr(), ws.numel(), st))
+            if self.kernel_events is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                self.kernel_events.append((ev0, ev1))
+            _lib.check(L.ppo_grad_reduce(self.state_dim, self.action_dim, ws.data_ptr(), ws.numel(),
+                                         opt.grad.data_ptr(), st))
+            _dist.all_reduce_sum(opt.grad)
+            if debug and e == 0:
+                dbg["grad"] = opt.grad[:P].clone()
+                dbg["returns_norm"] = returns.clone()
+                dbg["advantages"] = adv.clone()
+                dbg["moments"] = moments.clone()
+            opt.zero_grad()
+            opt.step(loss_out=losses[e:e + 1])
+        self.last_loss = losses
+        self.debug_outputs = dbg
+
+        # Copy new weights into old policy (PPO.py:248)
+        self.policy_old.flat.copy_(self.policy.flat)
+
+        # clear buffer (PPO.py:251)
+        self.buffer.clear()
+
+    # ------------------------------------------------------------------ checkpoints (PPO.py:253-258)
+    def save(self, checkpoint_path):
+        torch.save({k: v.detach().cpu().clone() for k, v in self.policy_old.state_dict().items()},
+                   checkpoint_path)
+
+    def load(self, checkpoint_path):
+        self.policy_old.load_state_dict(torch.load(checkpoint_path, map_location=lambda storage, loc: storage))
+        self.policy.load_state_dict(torch.load(checkpoint_path, map_location=lambda storage, loc: storage))

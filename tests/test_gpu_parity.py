@@ -1,0 +1,376 @@
+"""Parity of the HIP engine (through the C ABI) with the reference: golden vectors captured from
+the reference itself, and the CPU restatement in oracle/ on seeded inputs.  Needs an MI355X."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, UPDATE_CASES, case_params, load_case, max_abs, rel_err
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_REL = 1e-5     # returns / advantages / log-probs / loss (north star)
+TOL_PARAM = 1e-4   # parameters after an update
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ppo_amd import _lib, ppo
+    assert os.path.exists(_lib.LIB_PATH)
+    return ppo, _lib
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def scan_flat(_lib, rewards, terminals, gamma, f64=True):
+    n = len(rewards)
+    L = _lib.lib()
+    r = dev(rewards, torch.float64 if f64 else torch.float32)
+    t = dev(np.asarray(terminals, dtype=np.uint8))
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    mom = torch.zeros(3, dtype=torch.float64, device="cuda")
+    ws = torch.empty(L.ppo_workspace_bytes(4, 2, n), dtype=torch.uint8, device="cuda")
+    _lib.check(L.ppo_returns_scan_flat(r.data_ptr(), int(f64), t.data_ptr(), n, float(gamma),
+                                       out.data_ptr(), mom.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return out, mom
+
+
+def normalize(_lib, returns, values, mom):
+    n = returns.numel()
+    rn = torch.empty_like(returns)
+    adv = torch.empty_like(returns)
+    _lib.check(_lib.lib().ppo_normalize_advantage(returns.data_ptr(), values.data_ptr(), n,
+                                                  mom.data_ptr(), rn.data_ptr(), adv.data_ptr(),
+                                                  _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return rn, adv
+
+
+# ------------------------------------------------------------------------------ returns
+def test_scan_flat_golden(eng):
+    _, _lib = eng
+    d = np.load(os.path.join(GOLDEN, "scan_cases.npz"))
+    for i in range(int(d["n_cases"])):
+        out, mom = scan_flat(_lib, d[f"{i}/rewards"], d[f"{i}/terminals"], float(d[f"{i}/gamma"]))
+        want = d[f"{i}/returns32"]
+        assert np.array_equal(out.cpu().numpy(), want), f"case {i}: returns not bit-exact"
+        n, mean, m2 = mom.cpu().numpy()
+        assert n == len(want)
+        std = np.sqrt(m2 / (n - 1))
+        assert rel_err(mean, d[f"{i}/ret_mean"], floor=float(np.abs(want).mean())) < TOL_REL
+        assert rel_err(std, d[f"{i}/ret_std"]) < TOL_REL
+        rn, _ = normalize(_lib, out, torch.zeros_like(out), mom)
+        assert rel_err(rn.cpu().numpy(), d[f"{i}/returns_norm"]) < TOL_REL
+
+
+@pytest.mark.parametrize("T,p", [(1, 0.0), (2, 0.5), (2047, 0.01), (2048, 0.0), (2049, 1.0),
+                                 (524288, 1 / 200), (1000003, 1e-4)])
+def test_scan_flat_vs_oracle(eng, T, p):
+    _, _lib = eng
+    rng = np.random.default_rng(T)
+    r = rng.standard_normal(T).astype(np.float32)
+    term = rng.random(T) < p
+    want64 = O.returns_scan(r, term, 0.99)
+    out, mom = scan_flat(_lib, r, term, 0.99, f64=False)
+    got = out.cpu().numpy()
+    want = want64.astype(np.float32)
+    # carries cross blocks through re-associated fp64 arithmetic: identical after fp32 rounding
+    # except for (rare) double-rounding ties
+    assert rel_err(got, want) < 1e-6
+    assert (got != want).mean() < 1e-4
+    r32, mean, std, _ = O.normalize_returns(want64)
+    n, gmean, m2 = mom.cpu().numpy()
+    assert n == T
+    if T > 1:
+        assert abs(gmean - mean) <= 1e-5 * max(abs(float(mean)), float(std))
+        assert rel_err(np.sqrt(m2 / (T - 1)), std) < TOL_REL
+
+
+@pytest.mark.parametrize("N,T", [(1, 5), (7, 33), (300, 128), (4096, 128)])
+def test_scan_rows_vs_oracle(eng, N, T):
+    _, _lib = eng
+    L = _lib.lib()
+    rng = np.random.default_rng(N * 1000 + T)
+    r = rng.standard_normal((N, T)).astype(np.float32)
+    term = rng.random((N, T)) < 0.02
+    want = O.returns_scan_rows(r, term, 0.99).astype(np.float32)          # [N, T]
+    r_tn = dev(r.T.copy())
+    t_tn = dev(term.T.copy().astype(np.uint8))
+    out = torch.empty((T, N), dtype=torch.float32, device="cuda")
+    mom = torch.zeros(3, dtype=torch.float64, device="cuda")
+    ws = torch.empty(L.ppo_workspace_bytes(4, 2, N * T), dtype=torch.uint8, device="cuda")
+    _lib.check(L.ppo_returns_scan_rows(r_tn.data_ptr(), t_tn.data_ptr(), T, N, 0.99, out.data_ptr(),
+                                       mom.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().T, want)   # same serial order as the reference: exact
+    n, mean, m2 = mom.cpu().numpy()
+    assert n == N * T
+    assert abs(mean - want.astype(np.float64).mean()) < 1e-9 * N * T
+    assert rel_err(m2, ((want.astype(np.float64) - want.astype(np.float64).mean()) ** 2).sum()) < 1e-9
+    # property: equals the flat scan of the env-major concatenation with row ends flagged terminal
+    forced = term.copy()
+    forced[:, -1] = True
+    flat, _ = scan_flat(_lib, r.reshape(-1), forced.reshape(-1), 0.99, f64=False)
+    assert rel_err(flat.cpu().numpy().reshape(N, T), want) < 1e-6
+
+
+# ------------------------------------------------------------------------------ evaluate / act
+def flat_params(P):
+    return dev(O.flatten_params(P))
+
+
+def var32(std):
+    return float(np.float32(float(std) * float(std)))
+
+
+def run_evaluate(_lib, P, S, A, cont, std, states, actions):
+    n = states.shape[0]
+    flat = flat_params(P)
+    x = dev(states, torch.float32)
+    a = dev(actions, torch.float32 if cont else torch.int32)
+    lp, v, ent = (torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(3))
+    _lib.check(_lib.lib().ppo_evaluate(flat.data_ptr(), S, A, int(cont), var32(std) if cont else 0.0,
+                                       x.data_ptr(), a.data_ptr(), n, lp.data_ptr(), v.data_ptr(),
+                                       ent.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return lp.cpu().numpy(), v.cpu().numpy(), ent.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", UPDATE_CASES)
+def test_evaluate_golden(eng, name):
+    _, _lib = eng
+    d = load_case(name)
+    cont = bool(d["continuous"])
+    lp, v, ent = run_evaluate(_lib, case_params(d), int(d["S"]), int(d["A"]), cont,
+                              float(d["action_std"]), d["states"], d["actions"])
+    assert rel_err(lp, d["logprobs_e1"]) < TOL_REL
+    assert rel_err(v, d["state_values_e1"]) < TOL_REL
+    assert rel_err(ent, d["entropy_e1"]) < TOL_REL
+
+
+def test_shipped_checkpoints(eng):
+    _, _lib = eng
+    d = np.load(os.path.join(GOLDEN, "checkpoints.npz"))
+    for env in d["envs"]:
+        P = {k[len(env) + 7:]: d[k] for k in d.files if k.startswith(f"{env}/param/")}
+        cont = bool(d[f"{env}/continuous"])
+        lp, v, ent = run_evaluate(_lib, P, int(d[f"{env}/S"]), int(d[f"{env}/A"]), cont, 0.6,
+                                  d[f"{env}/states"], d[f"{env}/actions"])
+        assert rel_err(v, d[f"{env}/critic_out"]) < TOL_REL, env
+        assert rel_err(lp, d[f"{env}/logprobs"]) < TOL_REL, env
+        assert rel_err(ent, d[f"{env}/entropy"]) < TOL_REL, env
+
+
+@pytest.mark.parametrize("S,A,cont,N", [(4, 2, False, 4096), (8, 4, False, 1000), (26, 6, True, 4096),
+                                        (3, 1, True, 77), (40, 8, True, 513), (63, 7, False, 300)])
+def test_act_batched(eng, S, A, cont, N):
+    ppo, _lib = eng
+    torch.manual_seed(S * 100 + A)
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 1, 0.2, cont, 0.6 if cont else None)
+    x = torch.randn(N, S, device="cuda")
+    act = agent.select_action(x)
+    torch.cuda.synchronize()
+    b = agent.buffer
+    assert len(b.states) == N and len(b.actions) == N and len(b.logprobs) == N
+    P = {k: v.cpu().numpy() for k, v in agent.policy_old.state_dict().items()}
+    a_np = act.cpu().numpy()
+    lp_want, v_want = O.act_logprob_value(P, x.cpu().numpy(), a_np, cont, 0.6)
+    lp = b.rows("logprobs", 0, N).cpu().numpy()
+    v = b.rows("state_values", 0, N).cpu().numpy()
+    assert rel_err(lp, lp_want) < TOL_REL
+    assert rel_err(v, v_want) < TOL_REL
+    if cont:
+        _, _, ao = O.mlp_forward(P, "actor", x.cpu().numpy())
+        z = (a_np - np.tanh(ao)) / 0.6
+        if N * A > 2000:
+            assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05
+    else:
+        assert a_np.min() >= 0 and a_np.max() < A
+        if N >= 1000:
+            _, _, ao = O.mlp_forward(P, "actor", x.cpu().numpy())
+            p = np.exp(ao - ao.max(-1, keepdims=True))
+            p /= p.sum(-1, keepdims=True)
+            freq = np.bincount(a_np, minlength=A) / N
+            assert np.abs(freq - p.mean(0)).max() < 0.05
+
+
+def test_select_action_reference_surface(eng):
+    ppo, _ = eng
+    agent = ppo.PPO(4, 2, 3e-4, 1e-3, 0.99, 2, 0.2, False, None)
+    a = agent.select_action(np.zeros(4))
+    assert isinstance(a, int) and a in (0, 1)
+    agent.buffer.rewards.append(1.0)
+    agent.buffer.is_terminals.append(False)
+    assert agent.buffer.states[0].shape == (4,) and agent.buffer.actions[0].dtype == torch.int64
+    assert agent.buffer.state_values[0].shape == (1,) and agent.buffer.logprobs[0].shape == ()
+    agent.select_action(np.ones(4))
+    agent.buffer.rewards.append(0.5)
+    agent.buffer.is_terminals.append(True)
+    agent.update()
+    assert len(agent.buffer.states) == 0 and len(agent.buffer.rewards) == 0
+    cagent = ppo.PPO(3, 2, 3e-4, 1e-3, 0.99, 2, 0.2, True, 0.6)
+    a = cagent.select_action(np.zeros(3))
+    assert isinstance(a, np.ndarray) and a.shape == (2,) and a.dtype == np.float32
+    assert cagent.buffer.actions[0].shape == (1, 2) and cagent.buffer.logprobs[0].shape == (1,)
+    cagent.buffer.clear()
+    assert len(cagent.buffer.actions) == 0
+
+
+# ------------------------------------------------------------------------------ update
+def agent_from_case(ppo, d, K):
+    cont = bool(d["continuous"])
+    agent = ppo.PPO(int(d["S"]), int(d["A"]), float(d["lr_actor"]), float(d["lr_critic"]),
+                    float(d["gamma"]), K, float(d["eps_clip"]), cont,
+                    float(d["action_std"]) if cont else None)
+    sd = {k: torch.from_numpy(v) for k, v in case_params(d).items()}
+    agent.policy.load_state_dict(sd)
+    agent.policy_old.load_state_dict(sd)
+    agent.buffer.load_rollout(d["states"], d["actions"], d["old_logprobs"], d["old_values"],
+                              d["rewards"], d["terminals"])
+    return agent
+
+
+@pytest.mark.parametrize("name", UPDATE_CASES)
+def test_update_first_epoch_golden(eng, name):
+    ppo, _ = eng
+    d = load_case(name)
+    K = int(d["K_list"][0])
+    agent = agent_from_case(ppo, d, K)
+    agent.update(debug=True)
+    torch.cuda.synchronize()
+    g = agent.debug_outputs
+    T = int(d["T"])
+    n, mean, m2 = g["moments"].cpu().numpy()
+    assert n == T
+    assert rel_err(mean, d["ret_mean"], floor=float(np.abs(d["returns32"]).mean())) < TOL_REL
+    assert rel_err(np.sqrt(m2 / (T - 1)), d["ret_std"]) < TOL_REL
+    assert rel_err(g["returns_norm"].cpu().numpy(), d["returns_norm"]) < TOL_REL
+    assert rel_err(g["advantages"].cpu().numpy(), d["advantages"]) < TOL_REL
+    assert rel_err(g["logprobs"].cpu().numpy(), d["logprobs_e1"]) < TOL_REL
+    assert rel_err(g["state_values"].cpu().numpy(), d["state_values_e1"]) < TOL_REL
+    assert rel_err(g["entropy"].cpu().numpy(), d["entropy_e1"]) < TOL_REL
+    # per-sample loss = -surrogate + 0.5*mse - 0.01*entropy (PPO.py:240)
+    mse = float(((d["state_values_e1"].astype(np.float64) - d["returns_norm"]) ** 2).mean())
+    loss = -g["surrogate"].cpu().numpy() + np.float32(0.5 * mse) - np.float32(0.01) * g["entropy"].cpu().numpy()
+    assert rel_err(loss, d["loss_per_sample_e1"]) < TOL_REL
+    assert rel_err(agent.last_loss.cpu().numpy()[0], d["loss_mean_e1"]) < TOL_REL
+    flat_grad = g["grad"].cpu().numpy()
+    grads = O.unflatten_params(flat_grad, int(d["S"]), int(d["A"]))
+    for k in O.PARAM_KEYS:
+        want = d["grad_e1/" + k]
+        assert rel_err(grads[k], want, floor=float(np.abs(want).max())) < 1e-4, k
+    got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
+    worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
+    assert worst < TOL_PARAM, worst
+    old = {k: v.cpu().numpy() for k, v in agent.policy_old.state_dict().items()}
+    assert all(np.array_equal(old[k], got[k]) for k in O.PARAM_KEYS)       # PPO.py:248
+    assert agent.optimizer.step_count == K
+
+
+@pytest.mark.parametrize("name", UPDATE_CASES)
+def test_update_k_epochs_golden(eng, name):
+    ppo, _ = eng
+    d = load_case(name)
+    for K in d["K_list"][1:]:
+        K = int(K)
+        agent = agent_from_case(ppo, d, K)
+        agent.update()
+        torch.cuda.synchronize()
+        got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
+        worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
+        # K<=4: 1e-4.  K=30/80: fp32 summation-order noise amplified by Adam's sign-like early
+        # steps; torch-CPU vs numpy-CPU already differ by 1.2e-4 on the same data.
+        tol = TOL_PARAM if K <= 4 else 5e-4
+        assert worst < tol, (K, worst)
+        assert rel_err(agent.last_loss.cpu().numpy(), d[f"K{K}/loss_mean_all"]) < 1e-4, K
+
+
+def test_update_deterministic(eng):
+    ppo, _ = eng
+    d = load_case("c2_lunarlander")
+    outs = []
+    for _ in range(2):
+        agent = agent_from_case(ppo, d, 4)
+        agent.update()
+        outs.append(agent.policy.flat.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_batched_update_equals_flat_with_row_end_terminals(eng):
+    """N lockstep envs x T steps through the tensor-valued buffer facade == the oracle's flat
+    update of the env-major concatenation with every row end flagged terminal."""
+    ppo, _ = eng
+    S, A, N, T, K = 4, 2, 96, 33, 3
+    torch.manual_seed(5)
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, K, 0.2, False, None)
+    P0 = {k: v.cpu().numpy().copy() for k, v in agent.policy.state_dict().items()}
+    rng = np.random.default_rng(3)
+    xs, rs, ts = [], [], []
+    for t in range(T):
+        x = torch.from_numpy(rng.standard_normal((N, S)).astype(np.float32)).cuda()
+        agent.select_action(x)
+        r = rng.standard_normal(N).astype(np.float32)
+        done = rng.random(N) < 0.05
+        agent.buffer.rewards.append(torch.from_numpy(r).cuda())
+        agent.buffer.is_terminals.append(torch.from_numpy(done).cuda())
+        xs.append(x.cpu().numpy()); rs.append(r); ts.append(done)
+    b = agent.buffer
+    n = N * T
+    # time-major [T, N] rows -> env-major flat order for the oracle
+    tn = lambda a: a.reshape(T, N, *a.shape[1:]).swapaxes(0, 1).reshape(n, *a.shape[1:])
+    states = tn(b.rows("states", 0, n).cpu().numpy())
+    actions = tn(b.rows("actions", 0, n).cpu().numpy())
+    logp = tn(b.rows("logprobs", 0, n).cpu().numpy())
+    vals = tn(b.rows("state_values", 0, n).cpu().numpy())
+    rew = tn(np.stack(rs).reshape(n))
+    term = np.stack(ts)
+    term[-1, :] = True
+    term = tn(term.reshape(n))
+    st = O.adam_init(P0)
+    O.update(P0, st, states, actions, logp, vals, rew, term, 0.99, 0.2, K, 3e-4, 1e-3, False)
+    agent.update()
+    got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
+    assert max(max_abs(got[k], P0[k]) for k in O.PARAM_KEYS) < TOL_PARAM
+
+
+# ------------------------------------------------------------------------------ checkpoints / schedule
+def test_checkpoint_roundtrip(eng, tmp_path):
+    ppo, _lib = eng
+    d = np.load(os.path.join(GOLDEN, "checkpoints.npz"))
+    agent = ppo.PPO(4, 2, 3e-4, 1e-3, 0.99, 1, 0.2, False, None)
+    agent.load(os.path.join(GOLDEN, "ckpt_CartPole-v1.pth"))      # written by the reference's save()
+    env = "CartPole-v1"
+    lp, v, ent = agent.policy_old.evaluate(d[f"{env}/states"], d[f"{env}/actions"])
+    assert rel_err(lp.cpu().numpy(), d[f"{env}/logprobs"]) < TOL_REL
+    assert rel_err(v.cpu().numpy().reshape(-1), d[f"{env}/critic_out"]) < TOL_REL
+    out = tmp_path / "x.pth"
+    agent.save(str(out))
+    sd = torch.load(str(out))
+    ref = torch.load(os.path.join(GOLDEN, "ckpt_CartPole-v1.pth"))
+    assert list(sd.keys()) == list(ref.keys())
+    for k in sd:
+        assert sd[k].dtype == ref[k].dtype and sd[k].shape == ref[k].shape and torch.equal(sd[k], ref[k])
+
+
+def test_decay_schedule_on_device(eng, capsys):
+    ppo, _ = eng
+    with open(os.path.join(GOLDEN, "decay_sequence.json")) as f:
+        g = json.load(f)
+    agent = ppo.PPO(3, 2, 3e-4, 1e-3, 0.99, 1, 0.2, True, 0.6)
+    for want, var in zip(g["std"][1:], g["var"][1:]):
+        agent.decay_action_std(g["rate"], g["min"])
+        assert agent.action_std == want
+        assert np.array_equal(agent.policy_old.action_var.cpu().numpy(), np.asarray(var, dtype=np.float32))
+    capsys.readouterr()
