@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of one full PPO iteration (lockstep batched act over N
+synthetic envs x T steps -> Monte-Carlo return scan + normalisation -> K-epoch clipped update)
+on N GPUs of one node, weak scaling (fixed envs per GPU).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+         --master-port 29511 bench.py --gpus 8 --steps 5 --warmup 2
+
+A "step" is one full iteration over one batch of synthetic input.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[3]: synthetic vectorised CartPole, 4096 envs/GPU x 128 steps
+    "c4": dict(name="synthetic CartPole-shaped (S=4, A=2 discrete), 4096 envs/GPU x 128 steps, K=80",
+               S=4, A=2, continuous=False, std=None, n_envs=4096, horizon=128, K=80,
+               reward_kind=0, p_terminal=1.0 / 200.0),
+    # BASELINE.json configs[4]: HalfCheetah-shaped continuous (obs 26, act 6), 65536 envs/GPU
+    "c5": dict(name="synthetic HalfCheetah-shaped (S=26, A=6 continuous), 65536 envs/GPU x 128 steps, K=80",
+               S=26, A=6, continuous=True, std=0.6, n_envs=65536, horizon=128, K=80,
+               reward_kind=1, p_terminal=-1.0),
+}
+PEAK_FP32_TFLOPS = 157.3   # MI355X dense fp32 (vector = matrix) peak
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_sample_epoch(S, A):
+    F = 2 * S * 64 + 2 * 64 * 64 + 64 * (A + 1)          # MACs of one actor+critic forward
+    return 2 * (3 * F - 2 * S * 64)                      # fwd + wgrad + dgrad (no input gradient)
+
+
+def cpu_baseline(cfg, threads):
+    """The CPU restatement (oracle/, numpy) timed on a bounded sample of the same workload."""
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+    from oracle import ppo_oracle as O
+    S, A, cont, std, K = cfg["S"], cfg["A"], cfg["continuous"], cfg["std"], cfg["K"]
+    rng = np.random.default_rng(0)
+    shapes = O.param_shapes(S, A)
+    P = {k: (rng.standard_normal(s) * 0.1).astype(np.float32) for k, s in shapes.items()}
+    Ts, n_act, n_ep = 32768, 1500, 2
+    x = rng.standard_normal((Ts, S)).astype(np.float32)
+    acts = (rng.standard_normal((Ts, A)).astype(np.float32) if cont else rng.integers(0, A, Ts))
+    with threadpool_limits(limits=threads):
+        t0 = time.perf_counter()
+        for i in range(n_act):           # the reference acts one state per call (PPO.py:175-198)
+            O.act_logprob_value(P, x[i:i + 1], acts[i:i + 1], cont, std)
+        t_act = (time.perf_counter() - t0) / n_act
+        r = rng.standard_normal(Ts).astype(np.float32)
+        term = rng.random(Ts) < 1 / 200
+        t0 = time.perf_counter()
+        ret = O.returns_scan(r, term, 0.99)
+        _, _, _, rn = O.normalize_returns(ret)
+        t_scan = (time.perf_counter() - t0) / Ts
+        lp, v = O.act_logprob_value(P, x, acts, cont, std)
+        adv = rn - v
+        st = O.adam_init(P)
+        t0 = time.perf_counter()
+        for _ in range(n_ep):
+            _, g = O.ppo_loss_and_grads(P, x, acts, lp, adv, rn, 0.2, cont, std)
+            O.adam_step(P, g, st, 3e-4, 1e-3)
+        t_ep = (time.perf_counter() - t0) / (n_ep * Ts)
+    per_step = t_act + t_scan + K * t_ep
+    return {"value": 1.0 / per_step, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"numpy restatement: {n_act} single-state act calls, scan+normalise of {Ts} "
+                      f"steps, {n_ep} update epochs over {Ts} samples; extrapolated to K={K}",
+            "us_per_step": {"act": t_act * 1e6, "scan": t_scan * 1e6, "epoch": t_ep * 1e6}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--k-epochs", type=int, default=None)
+    ap.add_argument("--n-envs", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.k_epochs:
+        cfg["K"] = args.k_epochs
+    if args.n_envs:
+        cfg["n_envs"] = args.n_envs
+
+    import torch
+    import torch.distributed as td
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        from ppo_amd import _lib, ppo
+    L = _lib.lib()
+    S, A, N, T, K = cfg["S"], cfg["A"], cfg["n_envs"], cfg["horizon"], cfg["K"]
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, K, 0.2, cfg["continuous"], cfg["std"])
+    agent.buffer.reserve(N * T)
+    env_seed = 1234 + rank
+    it = [0]
+
+    def iteration(timed_phases=None):
+        st = _lib.stream_ptr()
+        base = it[0] * T
+        for t in range(T):
+            xs = agent.next_state_slot(N)
+            rs, ds = agent.buffer.claim_env_slots(N)
+            _lib.check(L.ppo_synth_env_step(xs.data_ptr(), rs.data_ptr(), ds.data_ptr(), N, S,
+                                            cfg["reward_kind"], cfg["p_terminal"], base + t, T,
+                                            env_seed, st))
+            agent.act_inplace(N)
+        if timed_phases is not None:
+            torch.cuda.synchronize()
+            timed_phases["rollout"] = time.perf_counter()
+        agent.update()
+        it[0] += 1
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        iteration()
+    agent.kernel_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    barrier()
+    dt = time.perf_counter() - t0
+    events = agent.kernel_events
+    agent.kernel_events = None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+
+    # one more iteration with a host sync between phases, for the per-phase split (untimed)
+    ph = {}
+    torch.cuda.synchronize()
+    p0 = time.perf_counter()
+    iteration(ph)
+    torch.cuda.synchronize()
+    p2 = time.perf_counter()
+    phases = {"rollout_ms": (ph["rollout"] - p0) * 1e3, "update_ms": (p2 - ph["rollout"]) * 1e3}
+
+    if rank == 0:
+        steps_total = N * T * world * args.steps
+        flops_launch = flops_per_sample_epoch(S, A) * N * T
+        achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "env-steps/sec (act+return scan+K-epoch update)",
+            "value": steps_total / dt, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": cfg["name"], "n_envs_per_gpu": N, "horizon": T, "K_epochs": K,
+                       "state_dim": S, "action_dim": A, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "fwdbwd_kernel", "achieved": achieved,
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "avg_launch_ms": kern_ms, "launches_timed": len(events),
+                         "flop_per_sample_epoch": flops_per_sample_epoch(S, A)},
+            "phases": phases,
+            "final_loss": float(agent.last_loss[-1].item()),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ batch of N lockstep envs per call: ``select_action(states[N, S])`` and tensor-va
 ``buffer.rewards.append(r[N])`` / ``buffer.is_terminals.append(done[N])``.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -25,7 +26,9 @@ print("=========================================================================
 # set device to cpu or cuda  (PPO.py:6-16)
 device = torch.device('cpu')
 if torch.cuda.is_available():
-    device = torch.device('cuda:0')
+    # one process per GPU under torch.distributed.run: rank-local device; cuda:0 otherwise (PPO.py:11)
+    device = torch.device('cuda:' + os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(device)
     torch.cuda.empty_cache()
     print("Device set to : " + str(torch.cuda.get_device_name(device)))
 else:
