@@ -56,10 +56,12 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // ------------------------------------------------------------------ tanh
-// |x| < 0.625: odd polynomial (Cephes tanhf coefficients, < 1 ulp there);
-// otherwise 1 - 2/(exp(2|x|)+1) with the accurate expf.  Max error ~1.5 ulp.
+// |x| < 0.625: odd polynomial x + x^3 P(x^2) (Cephes tanhf coefficients, < 1 ulp there);
+// otherwise 1 - 2 / (exp(2x) + 1) from v_exp_f32 / v_rcp_f32, which saturates correctly
+// (exp -> inf gives 1, exp -> 0 gives -1) and is within ~2.5 ulp there.  ~14 instructions.
+// The exp/rcp form alone (5 instructions) has an ABSOLUTE error of ~1.5e-7 near 0, which a
+// saturated softmax head (large output weights) amplifies past 1e-5 relative on the log-probs.
 __device__ __forceinline__ float tanh_f32(float x) {
-    const float ax = fabsf(x);
     const float z = x * x;
     float p = -5.70498872745e-3f;
     p = fmaf(p, z, 2.06390887954e-2f);
@@ -67,9 +69,10 @@ __device__ __forceinline__ float tanh_f32(float x) {
     p = fmaf(p, z, 1.33314422036e-1f);
     p = fmaf(p, z, -3.33332819422e-1f);
     const float small = fmaf(p * z, x, x);
-    const float e = __expf(2.0f * ax);
-    const float big = copysignf(1.0f - 2.0f / (e + 1.0f), x);
-    return ax < 0.625f ? small : big;
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x)
+    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+    const float big = fmaf(-2.0f, r, 1.0f);
+    return fabsf(x) < 0.625f ? small : big;
 }
 
 __device__ __forceinline__ f32x16 tanh16(f32x16 v) {

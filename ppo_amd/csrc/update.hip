@@ -58,11 +58,16 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     fill_net_lds(L, a.params, P, S, A, AOUT, true);
     __syncthreads();
 
-    f32x16 gW2[2][2], gW1[2][JT], gW3[2], gb2[2];
+    // output-layer wgrad: for <= 2 outputs the per-lane products dout[a] * H2 are cheaper on the
+    // VALU (A*32 FMAs per tile) than a 32-row MFMA tile that is almost all padding
+    constexpr bool L3_VALU = AOUT <= 2;
+    f32x16 gW2[2][2], gW1[2][JT], gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         gW3[i] = 0.f;
         gb2[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < (L3_VALU ? AOUT : 1); ++k) gW3v[k][i] = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) gW2[i][j] = 0.f;
 #pragma unroll
@@ -189,22 +194,30 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
         gb2[1] += dZ2[1];
 
         // ---------------- wgrad of the output layer: dW3[a, u] += sum_m dout[m, a] H2[m, u]
+        if constexpr (L3_VALU) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int k = 0; k < AOUT; ++k) {
+                gW3v[k][0] += dout[k] * H2[0];
+                gW3v[k][1] += dout[k] * H2[1];
+            }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
-        if (h == 0) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int k = 0; k < AOUT; ++k) stgA[c * STG_LD + k] = dout[k];
-        }
+                for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
+            if (h == 0) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int mm = 2 * s + h;
-            const float av = c < AOUT ? stgA[mm * STG_LD + c] : 0.f;
-            const float b0 = stgB[mm * STG_LD + c];
-            const float b1 = stgB[mm * STG_LD + 32 + c];
-            gW3[0] = mfma32(av, b0, gW3[0]);
-            gW3[1] = mfma32(av, b1, gW3[1]);
+                for (int k = 0; k < AOUT; ++k) stgA[c * STG_LD + k] = dout[k];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int mm = 2 * s + h;
+                const float av = c < AOUT ? stgA[mm * STG_LD + c] : 0.f;
+                const float b0 = stgB[mm * STG_LD + c];
+                const float b1 = stgB[mm * STG_LD + 32 + c];
+                gW3[0] = mfma32(av, b0, gW3[0]);
+                gW3[1] = mfma32(av, b1, gW3[1]);
+            }
         }
 
         // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
@@ -282,6 +295,22 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
             v += __shfl_xor(v, 16);
             gb2[t][r] = v;
         }
+    if constexpr (L3_VALU) {
+#pragma unroll
+        for (int k = 0; k < AOUT; ++k)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = gW3v[k][t][r];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    v += __shfl_xor(v, 16);
+                    gW3v[k][t][r] = v;
+                }
+    }
 #pragma unroll
     for (int k = 0; k < AOUT; ++k) {
         float v = gb3[k];
@@ -315,13 +344,25 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
                     }
                     if (c == 0) RED_PUT(o_b2 + out, gb2[i][r]);
                 }
+            if constexpr (L3_VALU) {
+                if (c == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                    for (int k = 0; k < AOUT; ++k)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int act_row = rho(r, h);
-                    if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (k < A) RED_PUT(o_w3 + k * HID + 32 * t + rho(r, h), gW3v[k][t][r]);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int act_row = rho(r, h);
+                        if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
+                    }
+            }
             if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
@@ -475,13 +516,19 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
                                 align_up((size_t)(FB_GRID / 2) * a.stride_actor * sizeof(float), 256));
     hipStream_t st = (hipStream_t)stream;
     const bool wide = state_dim + 1 > 32;
-    const bool a8 = action_dim > 4;
-    if (continuous) {
-        if (!wide) return a8 ? launch_fwdbwd<true, 8, 1>(a, st) : launch_fwdbwd<true, 4, 1>(a, st);
-        return a8 ? launch_fwdbwd<true, 8, 2>(a, st) : launch_fwdbwd<true, 4, 2>(a, st);
-    }
-    if (!wide) return a8 ? launch_fwdbwd<false, 8, 1>(a, st) : launch_fwdbwd<false, 4, 1>(a, st);
-    return a8 ? launch_fwdbwd<false, 8, 2>(a, st) : launch_fwdbwd<false, 4, 2>(a, st);
+    const int amax = action_dim <= 2 ? 2 : (action_dim <= 4 ? 4 : 8);
+#define FB_DISPATCH(C)                                                                   \
+    if (!wide) {                                                                         \
+        if (amax == 2) return launch_fwdbwd<C, 2, 1>(a, st);                             \
+        if (amax == 4) return launch_fwdbwd<C, 4, 1>(a, st);                             \
+        return launch_fwdbwd<C, 8, 1>(a, st);                                            \
+    }                                                                                    \
+    if (amax == 2) return launch_fwdbwd<C, 2, 2>(a, st);                                 \
+    if (amax == 4) return launch_fwdbwd<C, 4, 2>(a, st);                                 \
+    return launch_fwdbwd<C, 8, 2>(a, st);
+    if (continuous) { FB_DISPATCH(true) }
+    FB_DISPATCH(false)
+#undef FB_DISPATCH
 }
 
 extern "C" int ppo_grad_reduce(int state_dim, int action_dim, const void* workspace,
