@@ -56,12 +56,21 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // ------------------------------------------------------------------ tanh
-// |x| < 0.625: odd polynomial x + x^3 P(x^2) (Cephes tanhf coefficients, < 1 ulp there);
-// otherwise 1 - 2 / (exp(2x) + 1) from v_exp_f32 / v_rcp_f32, which saturates correctly
-// (exp -> inf gives 1, exp -> 0 gives -1) and is within ~2.5 ulp there.  ~14 instructions.
-// The exp/rcp form alone (5 instructions) has an ABSOLUTE error of ~1.5e-7 near 0, which a
-// saturated softmax head (large output weights) amplifies past 1e-5 relative on the log-probs.
-__device__ __forceinline__ float tanh_f32(float x) {
+// On gfx950 the fp32 MFMA runs on the same datapath as the fp32 VALU (measured: VALU fillers
+// between v_mfma_f32_32x32x2_f32 add their full issue time at 1, 2 and 4 waves per SIMD), so every
+// VALU instruction of the 128 tanh evaluations per sample is paid for in matrix throughput.
+// tanh(x) = 1 - 2 / (exp(2x) + 1) in four instructions (v_exp, v_add, v_rcp, v_fma); the factor
+// 2*log2(e) that v_exp_f32 (base 2) needs is folded into the layer's weights and bias when they are
+// staged into LDS.  Saturates correctly (exp -> inf gives 1, exp -> 0 gives -1).  Absolute error
+// <= ~1.5e-7 over the whole range, i.e. the rounding noise of a value near 1; the RELATIVE error
+// near 0 is not small, which nothing here needs (hidden units feed dot products, the Gaussian mean
+// feeds a difference).  -DPPO_TANH_ACCURATE selects a <= 2.5 ulp version (odd polynomial below
+// 0.625) at ~3x the instructions.
+#define TANH_PRESCALE 2.8853900817779268f  // 2 * log2(e)
+
+__device__ __forceinline__ float tanh_prescaled(float xs) {  // xs = x * TANH_PRESCALE
+#ifdef PPO_TANH_ACCURATE
+    const float x = xs * (1.0f / TANH_PRESCALE);
     const float z = x * x;
     float p = -5.70498872745e-3f;
     p = fmaf(p, z, 2.06390887954e-2f);
@@ -69,22 +78,26 @@ __device__ __forceinline__ float tanh_f32(float x) {
     p = fmaf(p, z, 1.33314422036e-1f);
     p = fmaf(p, z, -3.33332819422e-1f);
     const float small = fmaf(p * z, x, x);
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x)
-    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
-    const float big = fmaf(-2.0f, r, 1.0f);
-    return fabsf(x) < 0.625f ? small : big;
+    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f);
+    return fabsf(x) < 0.625f ? small : fmaf(-2.0f, r, 1.0f);
+#else
+    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f);
+    return fmaf(-2.0f, r, 1.0f);
+#endif
 }
 
-__device__ __forceinline__ f32x16 tanh16(f32x16 v) {
+__device__ __forceinline__ float tanh_f32(float x) { return tanh_prescaled(x * TANH_PRESCALE); }
+
+__device__ __forceinline__ f32x16 tanh16_prescaled(f32x16 v) {
     f32x16 o;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = tanh_f32(v[r]);
+    for (int r = 0; r < 16; ++r) o[r] = tanh_prescaled(v[r]);
     return o;
 }
 
 // ------------------------------------------------------------------ LDS image of one MLP
-// w1t: [2*KS1][64]  row k (< S: input k; == S: bias b1; > S: zero), column = hidden unit
-// w2t: [64][64]     [in][out]  (forward A operand: lanes run over `out`)
+// w1t: [2*KS1][64]  row k (< S: input k; == S: bias b1; > S: zero), column = hidden unit; x TANH_PRESCALE
+// w2t: [64][64]     [in][out]  (forward A operand: lanes run over `out`); x TANH_PRESCALE, as is b2
 // w2n: [64][64]     [out][in]  (dgrad A operand: lanes run over `in`); absent for forward-only
 // b2 : [64], w3: [AOUT][64] (rows >= A zero), b3: [AOUT]
 struct NetLds {
@@ -123,14 +136,14 @@ __device__ inline void fill_net_lds(const NetLds& L, const float* __restrict__ p
         float v = 0.f;
         if (k < S) v = params[P.w1 + o * S + k];
         else if (k == S) v = params[P.b1 + o];
-        L.w1t[i] = v;
+        L.w1t[i] = v * TANH_PRESCALE;
     }
     for (int i = tid; i < HID * HID; i += nt) {
         const float v = params[P.w2 + i];  // W2[out = i>>6][in = i&63]
-        L.w2t[(i & 63) * HID + (i >> 6)] = v;
+        L.w2t[(i & 63) * HID + (i >> 6)] = v * TANH_PRESCALE;
         if (bwd) L.w2n[i] = v;
     }
-    for (int i = tid; i < HID; i += nt) L.b2[i] = params[P.b2 + i];
+    for (int i = tid; i < HID; i += nt) L.b2[i] = params[P.b2 + i] * TANH_PRESCALE;
     for (int i = tid; i < aout * HID; i += nt) L.w3[i] = (i >> 6) < A ? params[P.w3 + i] : 0.f;
     for (int i = tid; i < aout; i += nt) L.b3[i] = i < A ? params[P.b3 + i] : 0.f;
 }
@@ -151,8 +164,8 @@ __device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __res
         z0 = mfma32(a0, b, z0);
         z1 = mfma32(a1, b, z1);
     }
-    H1[0] = tanh16(z0);
-    H1[1] = tanh16(z1);
+    H1[0] = tanh16_prescaled(z0);
+    H1[1] = tanh16_prescaled(z1);
     f32x16 y0, y1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -171,8 +184,8 @@ __device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __res
             y1 = mfma32(a1, b, y1);
         }
     }
-    H2[0] = tanh16(y0);
-    H2[1] = tanh16(y1);
+    H2[0] = tanh16_prescaled(y0);
+    H2[1] = tanh16_prescaled(y1);
 }
 
 // o[a] = b3[a] + sum_u W3[a][u] * H2[u]; each lane sums its 32 units, the two halves are added.

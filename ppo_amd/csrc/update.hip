@@ -18,8 +18,25 @@
 #define FB_THREADS 256
 #define FB_WAVES 4
 #define FB_GRID 256  // one workgroup per CU; half per role
+#define STG_D 9                                               // row stride of the dout buffer
+#define STG_WAVE_FLOATS (3 * TILE_M * STG_LD + TILE_M * STG_D + 8)  // per-wave transposition space
+
+// Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
+// wave, written to a buffer registered with ppo_debug_set_stamps().  Never compiled into the product.
+#ifdef PPO_PHASE_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" void ppo_debug_set_stamps(void* p) { g_stamp_buf = (unsigned long long*)p; }
+#define STAMP_DECL unsigned long long st_acc[12] = {0}; unsigned long long st_prev = 0;
+#define STAMP_START { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[i] += _t - st_prev; st_prev = _t; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#endif
 
 struct FwdBwdArgs {
+    unsigned long long* stamps;
     const float* params;
     int S, A;
     float action_var;
@@ -53,9 +70,15 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
 
     const NetLds L = carve_net_lds(smem, S, AOUT, true);
     float* stg = smem + round4(net_lds_floats(S, AOUT, true));
-    float* stgA = stg + wave * (2 * TILE_M * STG_LD);
+    // per-wave transposition buffers [32 samples][STG_LD]: A = dZ2, B = H1, C = dZ1 (or H2 while the
+    // output layer's MFMA wgrad runs), D = dout [32][STG_D]
+    float* stgA = stg + wave * STG_WAVE_FLOATS;
     float* stgB = stgA + TILE_M * STG_LD;
+    float* stgC = stgB + TILE_M * STG_LD;
+    float* stgD = stgC + TILE_M * STG_LD;
     fill_net_lds(L, a.params, P, S, A, AOUT, true);
+    // the first tile's deferred wgrad MFMAs read these before anything was written: zeros add zero
+    for (int i = lane; i < STG_WAVE_FLOATS; i += 64) stgA[i] = 0.f;
     __syncthreads();
 
     // output-layer wgrad: for <= 2 outputs the per-lane products dout[a] * H2 are cheaper on the
@@ -77,16 +100,122 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
 #pragma unroll
     for (int k = 0; k < AOUT; ++k) gb3[k] = 0.f;
     double loss_acc = 0.0;
+    STAMP_DECL
+
+    // ---- the weight-gradient MFMAs of a tile are DEFERRED into the next tile's forward pass: their
+    // operands wait in LDS, they depend on nothing the forward computes, and issued one at a time
+    // between the tanh evaluations they run on the matrix pipe while the VALU does the tanh.
+    int64_t prev_m0 = a.n;  // first sample of the tile whose wgrads are pending (a.n = none)
+    // layer-2 wgrad, k-step s (samples 2s, 2s+1), output tile (i, j): dW2[o, in] += dZ2[m, o] H1[m, in]
+    auto wgrad2 = [&](int s, int i, int j) {
+        const int mm = 2 * s + h;
+        gW2[i][j] = mfma32(stgA[mm * STG_LD + 32 * i + c], stgB[mm * STG_LD + 32 * j + c], gW2[i][j]);
+    };
+    // layer-1 wgrad (+ bias as the ones column of X): dW1[o, in] += dZ1[m, o] X[m, in].
+    // xp[s][jt] = X_aug[sample 2s+h of the pending tile][input 32*jt + c], fetched at the top of
+    // the tile that executes it (no branch, clamped address: the loads issue back to back).
+    float xp[16][JT];
+    auto load_xp = [&]() {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int64_t gm = min(prev_m0 + 2 * s + h, a.n - 1);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const int in = 32 * jt + c;
+                const float v = a.states[gm * S + min(in, S - 1)];
+                xp[s][jt] = in < S ? v : (in == S ? 1.0f : 0.0f);
+            }
+        }
+    };
+    auto wgrad1 = [&](int s, int i, int jt) {
+        const int mm = 2 * s + h;
+        gW1[i][jt] = mfma32(stgC[mm * STG_LD + 32 * i + c], xp[s][jt], gW1[i][jt]);
+    };
+    // xf[s] = X_aug[this lane's sample][input 2s+h] of the tile about to run, fetched one tile ahead
+    constexpr int KS1MAX = 16 * JT;
+    const int ks1 = ks1_of(S);
+    float xf[KS1MAX];
+    auto load_xf = [&](int64_t t_m0) {
+        const int64_t mi = min(t_m0 + c, a.n - 1);
+#pragma unroll
+        for (int s = 0; s < KS1MAX; ++s) {
+            if (s < ks1) {
+                const int k = 2 * s + h;
+                const float v = a.states[mi * S + min(k, S - 1)];
+                xf[s] = k < S ? v : (k == S ? 1.0f : 0.0f);
+            }
+        }
+    };
 
     const int64_t n_tiles = (a.n + TILE_M - 1) / TILE_M;
-    for (int64_t tile = (int64_t)wg * FB_WAVES + wave; tile < n_tiles; tile += (int64_t)nwg * FB_WAVES) {
+    const int64_t tile0 = (int64_t)wg * FB_WAVES + wave, tstride = (int64_t)nwg * FB_WAVES;
+    load_xf(min(tile0, n_tiles - 1) * TILE_M);
+    for (int64_t tile = tile0; tile < n_tiles; tile += tstride) {
         const int64_t m0 = tile * TILE_M;
         const int64_t m = m0 + c;
         const bool valid = m < a.n;
+        STAMP_START
 
-        // ---------------- forward
+        // ---------------- forward, layer 1 (bias rides as the ones column)
         f32x16 H1[2], H2[2];
-        mlp_fwd_tile(L, a.states, S, m, valid, c, h, H1, H2);
+        {
+            f32x16 z0 = {0}, z1 = {0};
+#pragma unroll
+            for (int s = 0; s < KS1MAX; ++s) {
+                if (s < ks1) {
+                    const int k = 2 * s + h;
+                    z0 = mfma32(L.w1t[k * HID + c], xf[s], z0);
+                    z1 = mfma32(L.w1t[k * HID + 32 + c], xf[s], z1);
+                }
+            }
+            // issued only now so that the wait for xf above does not cover them:
+            load_xf(min(tile + tstride, n_tiles - 1) * TILE_M);  // next tile's, in flight all tile long
+            load_xp();                                           // pending tile's, used after layer 2
+            STAMP(0)
+            // tanh on the VALU || the pending layer-2 wgrad (64 MFMAs) on the matrix pipe
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                wgrad2(r, 0, 0);
+                H1[0][r] = tanh_prescaled(z0[r]);
+                wgrad2(r, 0, 1);
+                H1[1][r] = tanh_prescaled(z1[r]);
+                wgrad2(r, 1, 0);
+                wgrad2(r, 1, 1);
+            }
+        }
+        STAMP(1)
+        // ---------------- forward, layer 2
+        {
+            f32x16 y0, y1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] = L.b2[rho(r, h)];
+                y1[r] = L.b2[32 + rho(r, h)];
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = 32 * st + rho(r, h);
+                    const float b = H1[st][r];
+                    y0 = mfma32(L.w2t[k * HID + c], b, y0);
+                    y1 = mfma32(L.w2t[k * HID + 32 + c], b, y1);
+                }
+            }
+            STAMP(2)
+            // tanh || the pending layer-1 wgrad (32 * JT MFMAs)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) wgrad1(r, 0, jt);
+                H2[0][r] = tanh_prescaled(y0[r]);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) wgrad1(r, 1, jt);
+                H2[1][r] = tanh_prescaled(y1[r]);
+            }
+        }
+        prev_m0 = m0;
+        STAMP(3)
         float o[AOUT];
         out_layer<AOUT>(L, A, H2, h, o);
 
@@ -163,6 +292,7 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
             }
         }
 
+        STAMP(4)
         // ---------------- output layer backward (VALU): dZ2 = (W3^T dout) * (1 - H2^2)
         f32x16 dZ2[2];
 #pragma unroll
@@ -201,26 +331,26 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
                 gW3v[k][1] += dout[k] * H2[1];
             }
         } else {
+            // (the previous tile's dZ1 in stgC has been consumed by the deferred layer-1 wgrad above)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
+                for (int r = 0; r < 16; ++r) stgC[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
             if (h == 0) {
 #pragma unroll
-                for (int k = 0; k < AOUT; ++k) stgA[c * STG_LD + k] = dout[k];
+                for (int k = 0; k < AOUT; ++k) stgD[c * STG_D + k] = dout[k];
             }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int mm = 2 * s + h;
-                const float av = c < AOUT ? stgA[mm * STG_LD + c] : 0.f;
-                const float b0 = stgB[mm * STG_LD + c];
-                const float b1 = stgB[mm * STG_LD + 32 + c];
-                gW3[0] = mfma32(av, b0, gW3[0]);
-                gW3[1] = mfma32(av, b1, gW3[1]);
+                const float av = c < AOUT ? stgD[mm * STG_D + c] : 0.f;
+                gW3[0] = mfma32(av, stgC[mm * STG_LD + c], gW3[0]);
+                gW3[1] = mfma32(av, stgC[mm * STG_LD + 32 + c], gW3[1]);
             }
         }
 
-        // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
+        STAMP(5)
+        // ---------------- operands of the layer-2 wgrad (consumed during the next tile's forward)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -228,19 +358,8 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
                 stgA[c * STG_LD + 32 * t + rho(r, h)] = dZ2[t][r];
                 stgB[c * STG_LD + 32 * t + rho(r, h)] = H1[t][r];
             }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int mm = 2 * s + h;
-            const float a0 = stgA[mm * STG_LD + c];
-            const float a1 = stgA[mm * STG_LD + 32 + c];
-            const float b0 = stgB[mm * STG_LD + c];
-            const float b1 = stgB[mm * STG_LD + 32 + c];
-            gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
-            gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
-            gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
-            gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
-        }
 
+        STAMP(6)
         // ---------------- dgrad of layer 2: dH1^T = W2^T dZ2^T, then through tanh
         f32x16 dZ1[2];
         dZ1[0] = 0.f;
@@ -251,65 +370,59 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
             for (int r = 0; r < 16; ++r) {
                 const int k = 32 * st + rho(r, h);  // output unit of layer 2
                 const float b = dZ2[st][r];
-                const float a0 = L.w2n[k * HID + c];
-                const float a1 = L.w2n[k * HID + 32 + c];
-                dZ1[0] = mfma32(a0, b, dZ1[0]);
-                dZ1[1] = mfma32(a1, b, dZ1[1]);
+                dZ1[0] = mfma32(L.w2n[k * HID + c], b, dZ1[0]);
+                dZ1[1] = mfma32(L.w2n[k * HID + 32 + c], b, dZ1[1]);
             }
         }
+        STAMP(7)
         dZ1[0] = dZ1[0] * (1.0f - H1[0] * H1[0]);
         dZ1[1] = dZ1[1] * (1.0f - H1[1] * H1[1]);
-
-        // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
+        // ---------------- operand of the layer-1 wgrad (ditto)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stgA[c * STG_LD + 32 * t + rho(r, h)] = dZ1[t][r];
+            for (int r = 0; r < 16; ++r) stgC[c * STG_LD + 32 * t + rho(r, h)] = dZ1[t][r];
+        STAMP(8)
+    }
+    STAMP_START
+
+    // ---------------- the last tile's pending wgrads
+    load_xp();
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int mm = 2 * s + h;
-            const int64_t gm = m0 + mm;
-            const float a0 = stgA[mm * STG_LD + c];
-            const float a1 = stgA[mm * STG_LD + 32 + c];
+    for (int s = 0; s < 16; ++s) {
+        wgrad2(s, 0, 0);
+        wgrad2(s, 0, 1);
+        wgrad2(s, 1, 0);
+        wgrad2(s, 1, 1);
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const int in = 32 * jt + c;
-                float b = in == S ? 1.0f : 0.0f;
-                if (in < S && gm < a.n) b = a.states[gm * S + in];
-                gW1[0][jt] = mfma32(a0, b, gW1[0][jt]);
-                gW1[1][jt] = mfma32(a1, b, gW1[1][jt]);
-            }
+        for (int jt = 0; jt < JT; ++jt) {
+            wgrad1(s, 0, jt);
+            wgrad1(s, 1, jt);
         }
     }
 
+    STAMP(9)
     // ---------------- reduce lanes -> wave -> workgroup -> global partial row
+    // Per-lane partial sums (one per sample column) are summed over the 32 samples through the
+    // wave's own LDS space: written as [register][lane], read back as 32 consecutive floats per
+    // hidden unit, lane u ending up with unit u's total.  Fixed order, no cross-lane instructions.
+    auto colsum = [&](const f32x16 (&v)[2]) -> float {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = gb2[t][r];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 16);
-            gb2[t][r] = v;
-        }
+            for (int r = 0; r < 16; ++r) stgA[(16 * t + r) * STG_LD + lane] = v[t][r];
+        const int q = lane & 31;
+        const float* src = stgA + (16 * (lane >> 5) + (q & 3) + 4 * (q >> 3)) * STG_LD + 32 * ((q >> 2) & 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) acc += src[cc];
+        return acc;
+    };
+    const float db2_u = colsum(gb2);  // d/d b2[lane]
+    float dw3_u[L3_VALU ? AOUT : 1];  // d/d W3[k][lane] on the VALU path
     if constexpr (L3_VALU) {
 #pragma unroll
-        for (int k = 0; k < AOUT; ++k)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = gW3v[k][t][r];
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 4);
-                    v += __shfl_xor(v, 8);
-                    v += __shfl_xor(v, 16);
-                    gW3v[k][t][r] = v;
-                }
+        for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(gW3v[k]);
     }
 #pragma unroll
     for (int k = 0; k < AOUT; ++k) {
@@ -342,18 +455,12 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
                         if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
                         else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
                     }
-                    if (c == 0) RED_PUT(o_b2 + out, gb2[i][r]);
                 }
+            RED_PUT(o_b2 + lane, db2_u);
             if constexpr (L3_VALU) {
-                if (c == 0) {
 #pragma unroll
-                    for (int k = 0; k < AOUT; ++k)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                if (k < A) RED_PUT(o_w3 + k * HID + 32 * t + rho(r, h), gW3v[k][t][r]);
-                }
+                for (int k = 0; k < AOUT; ++k)
+                    if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -377,6 +484,13 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     float* dst = HEAD == HEAD_VALUE ? a.partial_critic + (size_t)wg * a.stride_critic
                                     : a.partial_actor + (size_t)wg * a.stride_actor;
     for (int i = threadIdx.x; i < P.n + 1; i += FB_THREADS) dst[i] = red[i];
+    STAMP(10)
+#ifdef PPO_PHASE_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* row = a.stamps + ((size_t)blockIdx.x * FB_WAVES + wave) * 16;
+        for (int i = 0; i < 12; ++i) row[i] = st_acc[i];
+    }
+#endif
 }
 
 template <bool CONT, int AMAX, int JT>
@@ -459,7 +573,7 @@ extern "C" int64_t ppo_param_count(int state_dim, int action_dim, int64_t* n_act
 
 static size_t fwdbwd_lds_bytes(int S, int amax) {
     const int net = round4(net_lds_floats(S, amax, true));
-    return (size_t)(net + FB_WAVES * 2 * TILE_M * STG_LD) * sizeof(float);
+    return (size_t)(net + FB_WAVES * STG_WAVE_FLOATS) * sizeof(float);
 }
 
 template <bool CONT, int AMAX, int JT>
@@ -491,6 +605,11 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
         return PPO_E_UNSUPPORTED;
     if (!workspace || workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
     FwdBwdArgs a;
+#ifdef PPO_PHASE_STAMPS
+    a.stamps = g_stamp_buf;
+#else
+    a.stamps = nullptr;
+#endif
     a.params = params;
     a.S = state_dim;
     a.A = action_dim;

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the fwd/bwd kernel (builds a -DPPO_PHASE_STAMPS library
+next to the product one; the stamps serialise the schedule, so read SHARES, not totals)."""
+import contextlib
+import ctypes
+import io
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import CONFIGS
+from ppo_amd import build as B
+
+LIB = os.path.join(ROOT, "ppo_amd", "libppo_hip_stamps.so")
+if "--build" in sys.argv:
+    srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DPPO_PHASE_STAMPS", "-shared"] + srcs + ["-o", LIB])
+    sys.exit(0)
+
+from ppo_amd import _lib
+_lib.LIB_PATH = LIB
+with contextlib.redirect_stdout(io.StringIO()):
+    from ppo_amd import ppo
+cfg = dict(CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c4"])
+S, A, N, T = cfg["S"], cfg["A"], cfg["n_envs"], cfg["horizon"]
+L = _lib.lib()
+torch.manual_seed(0)
+agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 3, 0.2, cfg["continuous"], cfg["std"])
+agent.buffer.reserve(N * T)
+for t in range(T):
+    xs = agent.next_state_slot(N)
+    rs, ds = agent.buffer.claim_env_slots(N)
+    _lib.check(L.ppo_synth_env_step(xs.data_ptr(), rs.data_ptr(), ds.data_ptr(), N, S, cfg["reward_kind"],
+                                    cfg["p_terminal"], t, T, 1234, _lib.stream_ptr()))
+    agent.act_inplace(N)
+stamps = torch.zeros(1024 * 16, dtype=torch.int64, device="cuda")
+ctypes.CDLL(LIB).ppo_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+agent.kernel_events = []
+agent.update()
+torch.cuda.synchronize()
+print("ms per launch:", [round(a.elapsed_time(b), 4) for a, b in agent.kernel_events])
+st = stamps.view(1024, 16).cpu().numpy().astype(float)
+names = ["L1 fwd + loads", "tanh1 || wgrad2(prev)", "L2 fwd", "tanh2 || wgrad1(prev)", "out layer + head",
+         "dZ2 + L3 wgrad", "stage dZ2,H1", "dgrad L2", "dZ1 + stage", "flush", "epilogue reduce"]
+for role, sel in (("actor", slice(0, None, 2)), ("critic", slice(1, None, 2))):
+    rows = st.reshape(256, 4, 16)[sel].reshape(-1, 16)
+    tot = rows[:, :11].sum(1).mean()
+    print(f"{role}: mean cycles/wave {tot:.0f}")
+    for i, nme in enumerate(names):
+        print(f"   {nme:26s} {rows[:, i].mean():10.0f}  {100 * rows[:, i].mean() / tot:5.1f}%")
