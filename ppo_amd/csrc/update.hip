@@ -1,42 +1,37 @@
 // K-epoch update: fused evaluate + clipped-surrogate loss + backward (one launch per epoch),
 // deterministic gradient reduction, two-learning-rate Adam.
 //
-// fwdbwd kernel: 256 workgroups of 4 waves, even workgroups train the actor, odd ones the critic
-// (the two MLPs share no parameters and their loss terms are independent given the precomputed
-// advantages, PPO.py:221,240).  A wave owns tiles of 32 samples and keeps, across all its tiles,
-// the weight-gradient accumulators of its MLP in MFMA accumulator registers:
-//   forward   Z^T[64, 32] = W[64, K] X^T[K, 32]      (activations stay in registers, sample on lane)
-//   dgrad     dH^T[64,32] = W^T[64,64] dZ^T[64,32]   (ditto)
-//   wgrad     dW[64, K]  += dZ^T[64,32] X[32, K]     (reduction over samples = over lanes: both
-//             operands are transposed through a per-wave LDS buffer with an odd row stride)
-// Bias gradients: layer 1 rides in the wgrad as a ones column of X; layer 2 is summed per lane and
-// reduced across lanes once at the end; the output layer's likewise.
+// fwdbwd kernel.  256 workgroups (one per CU) of 8 waves; even workgroups train the actor, odd ones
+// the critic (the two MLPs share no parameters and, given the precomputed advantages, their loss
+// terms are independent: PPO.py:221,240).  On gfx950 the fp32 MFMA runs on the fp32 VALU datapath
+// (tools/ubench/mfma_valu_overlap.hip: VALU work between MFMAs adds its full issue time at any
+// occupancy), so the kernel's time is (MFMA count x 64 cycles) + (every other instruction), and the
+// design goal is (a) as few non-MFMA instructions as possible and (b) two waves per SIMD so that
+// one wave's LDS / global / MFMA-result latencies are filled by the other's instructions.
+// A workgroup is 4 PAIRS of waves; pair p = waves p (forward wave) and p + 4 (backward wave) share
+// tiles of 32 samples:
+//   forward wave   layer 1, tanh, layer 2, tanh, output layer, distribution head, loss, gradient
+//                  w.r.t. the head inputs, dZ2 = (W3^T dout)(1 - H2^2); keeps the output layer's
+//                  and b2's gradient sums; hands dZ2 and H1 to its partner through LDS, transposed
+//                  ([sample][unit], odd row stride);
+//   backward wave  dgrad dH1^T = W2^T dZ2^T, dZ1, and the two big weight gradients
+//                  dW2 += dZ2^T H1, dW1 += dZ1^T [X 1], accumulated across all its tiles in MFMA
+//                  accumulator registers.
+// The orientation keeps the sample on the MFMA lane (ppo_common.h), so forward and dgrad chain
+// through registers and only the weight gradients - reductions over samples - go through LDS.
+// Two workgroup barriers per tile order the hand-off; while the backward wave works on tile i the
+// forward wave already runs the forward pass of tile i + 1.
 // Nothing is accumulated with atomics: per-wave -> per-workgroup (fixed wave order through LDS) ->
 // ppo_grad_reduce (fixed workgroup order), so results are bit-reproducible run to run.
 #include "ppo_common.h"
 
-#define FB_THREADS 256
-#define FB_WAVES 4
-#define FB_GRID 256  // one workgroup per CU; half per role
-#define STG_D 9                                               // row stride of the dout buffer
-#define STG_WAVE_FLOATS (3 * TILE_M * STG_LD + TILE_M * STG_D + 8)  // per-wave transposition space
-
-// Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
-// wave, written to a buffer registered with ppo_debug_set_stamps().  Never compiled into the product.
-#ifdef PPO_PHASE_STAMPS
-static unsigned long long* g_stamp_buf = nullptr;
-extern "C" void ppo_debug_set_stamps(void* p) { g_stamp_buf = (unsigned long long*)p; }
-#define STAMP_DECL unsigned long long st_acc[12] = {0}; unsigned long long st_prev = 0;
-#define STAMP_START { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[i] += _t - st_prev; st_prev = _t; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define STAMP_DECL
-#define STAMP_START
-#define STAMP(i)
-#endif
+#define FB_PAIRS 4
+#define FB_THREADS (FB_PAIRS * 2 * 64)
+#define FB_GRID 256                                    // one workgroup per CU; half per role
+#define STG_D 9                                        // row stride of the dout buffer
+#define STG_PAIR_FLOATS (3 * TILE_M * STG_LD + TILE_M * STG_D + 8)  // per-pair transposition space
 
 struct FwdBwdArgs {
-    unsigned long long* stamps;
     const float* params;
     int S, A;
     float action_var;
@@ -58,6 +53,100 @@ struct FwdBwdArgs {
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
+// ---------------------------------------------------------------------------- head + loss
+// Distribution head, PPO.py:233-240 loss terms and the gradient w.r.t. the head's inputs for one
+// sample per lane (both half-waves hold the same sample and compute the same values).
+template <int HEAD, int AOUT>
+__device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const float (&o)[AOUT],
+                                               int64_t m, bool valid, bool writer,
+                                               float (&dout)[AOUT], double& loss_acc) {
+    if constexpr (HEAD == HEAD_VALUE) {
+        // 0.5 * MseLoss(state_values, rewards), PPO.py:240; d/dV of its mean = (V - R)/n
+        const float R = valid ? a.ret[m] : 0.f;
+        const float diff = o[0] - R;
+        dout[0] = valid ? diff * a.inv_n : 0.f;
+        if (valid && writer) {
+            loss_acc += (double)diff * (double)diff;
+            if (a.out_val) a.out_val[m] = o[0];
+        }
+    } else {
+        const float old_lp = valid ? a.old_logp[m] : 0.f;
+        const float adv = valid ? a.adv[m] : 0.f;
+        float logp, ent;
+        CatOut<AOUT> cat;
+        GaussOut<AOUT> gs;
+        int action = 0;
+        if constexpr (HEAD == HEAD_CATEGORICAL) {
+            action = valid ? reinterpret_cast<const int*>(a.actions)[m] : 0;
+            categorical_head<AOUT>(o, A, cat);
+            logp = cat.L[0];
+#pragma unroll
+            for (int k = 1; k < AOUT; ++k) logp = (k == action) ? cat.L[k] : logp;
+            ent = cat.ent;
+        } else {
+            float act[AOUT];
+            const float* ap = reinterpret_cast<const float*>(a.actions);
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) act[k] = (valid && k < A) ? ap[m * A + k] : 0.f;
+            gaussian_head<AOUT>(o, A, a.action_var, act, gs);
+            logp = gs.logp;
+            ent = gs.ent;
+        }
+        const float ratio = expf(logp - old_lp);
+        const float s1 = ratio * adv;
+        const float s2 = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi) * adv;
+        const float surr = fminf(s1, s2);
+        // torch.min splits ties 1/2 + 1/2 and clamp passes gradient on the closed interval: inside
+        // the clip range the whole gradient flows through ratio; outside it only when the
+        // unclipped branch is the smaller one.
+        const bool inside = ratio >= a.clip_lo && ratio <= a.clip_hi;
+        const bool gate = inside || (adv >= 0.f ? ratio <= a.clip_hi : ratio >= a.clip_lo);
+        const float dlogp = (valid && gate) ? -(adv * ratio) * a.inv_n : 0.f;
+        const float dent = valid ? -0.01f * a.inv_n : 0.f;
+        if constexpr (HEAD == HEAD_CATEGORICAL) {
+            float pa = cat.pass[0], wq = 0.f;
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) {
+                pa = (k == action) ? cat.pass[k] : pa;
+                if (k < A) wq += (cat.L[k] + cat.pass[k]) * cat.q[k];
+            }
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) {
+                const float onehot = (k == action) ? 1.f : 0.f;
+                const float dz_logp = pa * (onehot - cat.q[k]);
+                const float dz_ent = -(cat.q[k] * ((cat.L[k] + cat.pass[k]) - wq));
+                dout[k] = k < A ? dlogp * dz_logp + dent * dz_ent : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k)
+                dout[k] = k < A ? dlogp * (gs.zed[k] / gs.sigma) * (1.0f - gs.mu[k] * gs.mu[k]) : 0.f;
+        }
+        if (valid && writer) {
+            loss_acc += (double)(-surr - 0.01f * ent);
+            if (a.out_logp) a.out_logp[m] = logp;
+            if (a.out_ent) a.out_ent[m] = ent;
+            if (a.out_surr) a.out_surr[m] = surr;
+        }
+    }
+}
+
+// Sum of per-lane partials over the 32 sample columns through `buf` (>= 32*STG_LD floats, private
+// to the calling wave): written as [register][lane], read back as 32 consecutive floats per hidden
+// unit; lane u returns unit u's total.  Fixed order, no cross-lane instructions.
+__device__ __forceinline__ float colsum(float* buf, const f32x16 (&v)[2], int lane) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[(16 * t + r) * STG_LD + lane] = v[t][r];
+    const int q = lane & 31;
+    const float* src = buf + (16 * (lane >> 5) + (q & 3) + 4 * (q >> 3)) * STG_LD + 32 * ((q >> 2) & 1);
+    float acc = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) acc += src[cc];
+    return acc;
+}
+
 template <int HEAD, int AOUT, int JT>
 __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     const int S = a.S;
@@ -66,25 +155,34 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
                                            : net_layout(0, S, a.A);
     const int base = HEAD == HEAD_VALUE ? n_actor_params(S, a.A) : 0;
     const int wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int pair = wave & (FB_PAIRS - 1);
+    const bool is_fwd = wave < FB_PAIRS;
 
     const NetLds L = carve_net_lds(smem, S, AOUT, true);
     float* stg = smem + round4(net_lds_floats(S, AOUT, true));
-    // per-wave transposition buffers [32 samples][STG_LD]: A = dZ2, B = H1, C = dZ1 (or H2 while the
-    // output layer's MFMA wgrad runs), D = dout [32][STG_D]
-    float* stgA = stg + wave * STG_WAVE_FLOATS;
+    // per-pair transposition buffers [32 samples][STG_LD]: A = dZ2, B = H1 (H2 while the output
+    // layer's MFMA wgrad runs), C = dZ1 (private to the backward wave), D = dout [32][STG_D]
+    float* stgA = stg + pair * STG_PAIR_FLOATS;
     float* stgB = stgA + TILE_M * STG_LD;
     float* stgC = stgB + TILE_M * STG_LD;
     float* stgD = stgC + TILE_M * STG_LD;
     fill_net_lds(L, a.params, P, S, A, AOUT, true);
-    // the first tile's deferred wgrad MFMAs read these before anything was written: zeros add zero
-    for (int i = lane; i < STG_WAVE_FLOATS; i += 64) stgA[i] = 0.f;
     __syncthreads();
 
-    // output-layer wgrad: for <= 2 outputs the per-lane products dout[a] * H2 are cheaper on the
-    // VALU (A*32 FMAs per tile) than a 32-row MFMA tile that is almost all padding
-    constexpr bool L3_VALU = AOUT <= 2;
-    f32x16 gW2[2][2], gW1[2][JT], gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];
+    const int64_t n_tiles = (a.n + TILE_M - 1) / TILE_M;
+    const int64_t tstride = (int64_t)nwg * FB_PAIRS;
+    const int64_t tile0 = (int64_t)wg * FB_PAIRS + pair;
+    const int n_iter = (int)((n_tiles + tstride - 1) / tstride);  // same for every wave: barriers match
+    const int ks1 = ks1_of(S);
+    constexpr bool L3_VALU = AOUT <= 2;  // output-layer wgrad on the VALU (A*32 FMAs per tile)
+
+    // accumulators kept across all tiles (only the role that owns them touches them)
+    f32x16 gW2[2][2], gW1[2][JT];                             // backward wave
+    f32x16 gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];       // forward wave
+    float gb3[AOUT];
+    double loss_acc = 0.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         gW3[i] = 0.f;
@@ -96,386 +194,283 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
 #pragma unroll
         for (int j = 0; j < JT; ++j) gW1[i][j] = 0.f;
     }
-    float gb3[AOUT];
 #pragma unroll
     for (int k = 0; k < AOUT; ++k) gb3[k] = 0.f;
-    double loss_acc = 0.0;
-    STAMP_DECL
 
-    // ---- the weight-gradient MFMAs of a tile are DEFERRED into the next tile's forward pass: their
-    // operands wait in LDS, they depend on nothing the forward computes, and issued one at a time
-    // between the tanh evaluations they run on the matrix pipe while the VALU does the tanh.
-    int64_t prev_m0 = a.n;  // first sample of the tile whose wgrads are pending (a.n = none)
-    // layer-2 wgrad, k-step s (samples 2s, 2s+1), output tile (i, j): dW2[o, in] += dZ2[m, o] H1[m, in]
-    auto wgrad2 = [&](int s, int i, int j) {
-        const int mm = 2 * s + h;
-        gW2[i][j] = mfma32(stgA[mm * STG_LD + 32 * i + c], stgB[mm * STG_LD + 32 * j + c], gW2[i][j]);
-    };
-    // layer-1 wgrad (+ bias as the ones column of X): dW1[o, in] += dZ1[m, o] X[m, in].
-    // xp[s][jt] = X_aug[sample 2s+h of the pending tile][input 32*jt + c], fetched at the top of
-    // the tile that executes it (no branch, clamped address: the loads issue back to back).
-    float xp[16][JT];
-    auto load_xp = [&]() {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int64_t gm = min(prev_m0 + 2 * s + h, a.n - 1);
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const int in = 32 * jt + c;
-                const float v = a.states[gm * S + min(in, S - 1)];
-                xp[s][jt] = in < S ? v : (in == S ? 1.0f : 0.0f);
-            }
-        }
-    };
-    auto wgrad1 = [&](int s, int i, int jt) {
-        const int mm = 2 * s + h;
-        gW1[i][jt] = mfma32(stgC[mm * STG_LD + 32 * i + c], xp[s][jt], gW1[i][jt]);
-    };
-    // xf[s] = X_aug[this lane's sample][input 2s+h] of the tile about to run, fetched one tile ahead
-    constexpr int KS1MAX = 16 * JT;
-    const int ks1 = ks1_of(S);
-    float xf[KS1MAX];
-    auto load_xf = [&](int64_t t_m0) {
-        const int64_t mi = min(t_m0 + c, a.n - 1);
-#pragma unroll
-        for (int s = 0; s < KS1MAX; ++s) {
-            if (s < ks1) {
-                const int k = 2 * s + h;
-                const float v = a.states[mi * S + min(k, S - 1)];
-                xf[s] = k < S ? v : (k == S ? 1.0f : 0.0f);
-            }
-        }
-    };
-
-    const int64_t n_tiles = (a.n + TILE_M - 1) / TILE_M;
-    const int64_t tile0 = (int64_t)wg * FB_WAVES + wave, tstride = (int64_t)nwg * FB_WAVES;
-    load_xf(min(tile0, n_tiles - 1) * TILE_M);
-    for (int64_t tile = tile0; tile < n_tiles; tile += tstride) {
-        const int64_t m0 = tile * TILE_M;
-        const int64_t m = m0 + c;
-        const bool valid = m < a.n;
-        STAMP_START
-
-        // ---------------- forward, layer 1 (bias rides as the ones column)
-        f32x16 H1[2], H2[2];
-        {
-            f32x16 z0 = {0}, z1 = {0};
+    if (is_fwd) {
+        // ======================================================================= forward wave
+        // xf[s] = X_aug[this lane's sample][input 2s+h] (1 at input S, 0 beyond), fetched one tile
+        // ahead.  Row pointer + constant offsets: one instruction per load.
+        constexpr int KS1MAX = 16 * JT;
+        float xf[KS1MAX];
+        const int half_s = S >> 1;  // steps below this one read two real inputs
+        auto load_xf = [&](int64_t t_m0) {
+            const int64_t mi = min(t_m0 + c, a.n - 1);
+            const float* row = a.states + mi * S + h;
 #pragma unroll
             for (int s = 0; s < KS1MAX; ++s) {
-                if (s < ks1) {
-                    const int k = 2 * s + h;
-                    z0 = mfma32(L.w1t[k * HID + c], xf[s], z0);
-                    z1 = mfma32(L.w1t[k * HID + 32 + c], xf[s], z1);
-                }
+                if (s < half_s) xf[s] = row[2 * s];
+                else if (s == half_s) xf[s] = (S & 1) ? (h == 0 ? row[2 * s] : 1.0f) : (h == 0 ? 1.0f : 0.0f);
             }
-            // issued only now so that the wait for xf above does not cover them:
-            load_xf(min(tile + tstride, n_tiles - 1) * TILE_M);  // next tile's, in flight all tile long
-            load_xp();                                           // pending tile's, used after layer 2
-            STAMP(0)
-            // tanh on the VALU || the pending layer-2 wgrad (64 MFMAs) on the matrix pipe
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                wgrad2(r, 0, 0);
-                H1[0][r] = tanh_prescaled(z0[r]);
-                wgrad2(r, 0, 1);
-                H1[1][r] = tanh_prescaled(z1[r]);
-                wgrad2(r, 1, 0);
-                wgrad2(r, 1, 1);
-            }
-        }
-        STAMP(1)
-        // ---------------- forward, layer 2
-        {
-            f32x16 y0, y1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                y0[r] = L.b2[rho(r, h)];
-                y1[r] = L.b2[32 + rho(r, h)];
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = 32 * st + rho(r, h);
-                    const float b = H1[st][r];
-                    y0 = mfma32(L.w2t[k * HID + c], b, y0);
-                    y1 = mfma32(L.w2t[k * HID + 32 + c], b, y1);
-                }
-            }
-            STAMP(2)
-            // tanh || the pending layer-1 wgrad (32 * JT MFMAs)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) wgrad1(r, 0, jt);
-                H2[0][r] = tanh_prescaled(y0[r]);
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) wgrad1(r, 1, jt);
-                H2[1][r] = tanh_prescaled(y1[r]);
-            }
-        }
-        prev_m0 = m0;
-        STAMP(3)
-        float o[AOUT];
-        out_layer<AOUT>(L, A, H2, h, o);
+        };
+        load_xf(min(tile0, n_tiles - 1) * TILE_M);
+        for (int it = 0; it < n_iter; ++it) {
+            const int64_t tile = tile0 + (int64_t)it * tstride;
+            const int64_t m0 = tile * TILE_M;
+            const int64_t m = m0 + c;
+            const bool valid = m < a.n;
 
-        // ---------------- head, loss, gradient w.r.t. the pre-head outputs
-        float dout[AOUT];
-        if constexpr (HEAD == HEAD_VALUE) {
-            // 0.5 * MseLoss(state_values, rewards), PPO.py:240; d/dV of its mean = (V - R)/n
-            const float R = valid ? a.ret[m] : 0.f;
-            const float diff = o[0] - R;
-            dout[0] = valid ? diff * a.inv_n : 0.f;
-            if (valid && h == 0) {
-                loss_acc += (double)diff * (double)diff;
-                if (a.out_val) a.out_val[m] = o[0];
-            }
-        } else {
-            const float old_lp = valid ? a.old_logp[m] : 0.f;
-            const float adv = valid ? a.adv[m] : 0.f;
-            float logp, ent;
-            CatOut<AOUT> cat;
-            GaussOut<AOUT> gs;
-            int action = 0;
-            if constexpr (HEAD == HEAD_CATEGORICAL) {
-                action = valid ? reinterpret_cast<const int*>(a.actions)[m] : 0;
-                categorical_head<AOUT>(o, A, cat);
-                logp = cat.L[0];
+            // ---------------- layer 1 (bias rides as the ones column of X)
+            f32x16 H1[2], H2[2];
+            {
+                f32x16 z0 = {0}, z1 = {0};
 #pragma unroll
-                for (int k = 1; k < AOUT; ++k) logp = (k == action) ? cat.L[k] : logp;
-                ent = cat.ent;
-            } else {
-                float act[AOUT];
-                const float* ap = reinterpret_cast<const float*>(a.actions);
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k) act[k] = (valid && k < A) ? ap[m * A + k] : 0.f;
-                gaussian_head<AOUT>(o, A, a.action_var, act, gs);
-                logp = gs.logp;
-                ent = gs.ent;
-            }
-            // PPO.py:233-240
-            const float ratio = expf(logp - old_lp);
-            const float s1 = ratio * adv;
-            const float s2 = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi) * adv;
-            const float surr = fminf(s1, s2);
-            // torch.min splits ties 1/2 + 1/2 and clamp passes gradient on the closed interval:
-            // inside the clip range the whole gradient flows through ratio; outside it only when
-            // the unclipped branch is the smaller one.
-            const bool inside = ratio >= a.clip_lo && ratio <= a.clip_hi;
-            const bool gate = inside || (adv >= 0.f ? ratio <= a.clip_hi : ratio >= a.clip_lo);
-            const float dlogp = (valid && gate) ? -(adv * ratio) * a.inv_n : 0.f;
-            const float dent = valid ? -0.01f * a.inv_n : 0.f;
-            if constexpr (HEAD == HEAD_CATEGORICAL) {
-                float pa = cat.pass[0], wq = 0.f;
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k) {
-                    pa = (k == action) ? cat.pass[k] : pa;
-                    if (k < A) wq += (cat.L[k] + cat.pass[k]) * cat.q[k];
-                }
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k) {
-                    const float onehot = (k == action) ? 1.f : 0.f;
-                    const float dz_logp = pa * (onehot - cat.q[k]);
-                    const float dz_ent = -(cat.q[k] * ((cat.L[k] + cat.pass[k]) - wq));
-                    dout[k] = k < A ? dlogp * dz_logp + dent * dz_ent : 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k)
-                    dout[k] = k < A ? dlogp * (gs.zed[k] / gs.sigma) * (1.0f - gs.mu[k] * gs.mu[k]) : 0.f;
-            }
-            if (valid && h == 0) {
-                loss_acc += (double)(-surr - 0.01f * ent);
-                if (a.out_logp) a.out_logp[m] = logp;
-                if (a.out_ent) a.out_ent[m] = ent;
-                if (a.out_surr) a.out_surr[m] = surr;
-            }
-        }
-
-        STAMP(4)
-        // ---------------- output layer backward (VALU): dZ2 = (W3^T dout) * (1 - H2^2)
-        f32x16 dZ2[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k) {
-                    if (k < A) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[k * HID + 32 * t + 8 * q + 4 * h]);
-                        g0 = fmaf(w.x, dout[k], g0);
-                        g1 = fmaf(w.y, dout[k], g1);
-                        g2 = fmaf(w.z, dout[k], g2);
-                        g3 = fmaf(w.w, dout[k], g3);
+                for (int s = 0; s < KS1MAX; ++s) {
+                    if (s < ks1) {
+                        const int k = 2 * s + h;
+                        z0 = mfma32(L.w1t[k * HID + c], xf[s], z0);
+                        z1 = mfma32(L.w1t[k * HID + 32 + c], xf[s], z1);
                     }
                 }
-                dZ2[t][4 * q + 0] = g0 * (1.0f - H2[t][4 * q + 0] * H2[t][4 * q + 0]);
-                dZ2[t][4 * q + 1] = g1 * (1.0f - H2[t][4 * q + 1] * H2[t][4 * q + 1]);
-                dZ2[t][4 * q + 2] = g2 * (1.0f - H2[t][4 * q + 2] * H2[t][4 * q + 2]);
-                dZ2[t][4 * q + 3] = g3 * (1.0f - H2[t][4 * q + 3] * H2[t][4 * q + 3]);
+                load_xf(min(tile + tstride, n_tiles - 1) * TILE_M);  // next tile's, in flight all tile long
+                H1[0] = tanh16_prescaled(z0);
+                H1[1] = tanh16_prescaled(z1);
             }
-        }
-        if (h == 0) {
+            // ---------------- layer 2
+            {
+                f32x16 y0, y1;
 #pragma unroll
-            for (int k = 0; k < AOUT; ++k) gb3[k] += dout[k];
-        }
-        gb2[0] += dZ2[0];
-        gb2[1] += dZ2[1];
+                for (int r = 0; r < 16; ++r) {
+                    y0[r] = L.b2[rho(r, h)];
+                    y1[r] = L.b2[32 + rho(r, h)];
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = 32 * st + rho(r, h);
+                        const float b = H1[st][r];
+                        y0 = mfma32(L.w2t[k * HID + c], b, y0);
+                        y1 = mfma32(L.w2t[k * HID + 32 + c], b, y1);
+                    }
+                }
+                H2[0] = tanh16_prescaled(y0);
+                H2[1] = tanh16_prescaled(y1);
+            }
+            float o[AOUT];
+            out_layer<AOUT>(L, A, H2, h, o);
 
-        // ---------------- wgrad of the output layer: dW3[a, u] += sum_m dout[m, a] H2[m, u]
-        if constexpr (L3_VALU) {
-#pragma unroll
-            for (int k = 0; k < AOUT; ++k) {
-                gW3v[k][0] += dout[k] * H2[0];
-                gW3v[k][1] += dout[k] * H2[1];
-            }
-        } else {
-            // (the previous tile's dZ1 in stgC has been consumed by the deferred layer-1 wgrad above)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) stgC[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
+            // ---------------- head, loss, gradient w.r.t. the pre-head outputs
+            float dout[AOUT];
+            head_loss_grad<HEAD, AOUT>(a, A, o, m, valid, h == 0, dout, loss_acc);
             if (h == 0) {
 #pragma unroll
-                for (int k = 0; k < AOUT; ++k) stgD[c * STG_D + k] = dout[k];
+                for (int k = 0; k < AOUT; ++k) gb3[k] += dout[k];
             }
+            if constexpr (L3_VALU) {  // dW3[k, u] += dout[m, k] * H2[m, u], per-lane partials
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) {
+                    gW3v[k][0] += dout[k] * H2[0];
+                    gW3v[k][1] += dout[k] * H2[1];
+                }
+            }
+
+            __syncthreads();  // the partner has finished reading the previous tile's buffers
+
+            if constexpr (!L3_VALU) {
+                // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u], H2
+                // transposed through stgB before H1 takes its place
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
+                if (h == 0) {
+#pragma unroll
+                    for (int k = 0; k < AOUT; ++k) stgD[c * STG_D + k] = dout[k];
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int mm = 2 * s + h;
+                    const float av = c < AOUT ? stgD[mm * STG_D + c] : 0.f;
+                    gW3[0] = mfma32(av, stgB[mm * STG_LD + c], gW3[0]);
+                    gW3[1] = mfma32(av, stgB[mm * STG_LD + 32 + c], gW3[1]);
+                }
+            }
+            // ---------------- output layer backward: dZ2 = (W3^T dout) * (1 - H2^2), handed over
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < AOUT; ++k) {
+                        if (k < A) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[k * HID + 32 * t + 8 * q + 4 * h]);
+                            g[0] = fmaf(w.x, dout[k], g[0]);
+                            g[1] = fmaf(w.y, dout[k], g[1]);
+                            g[2] = fmaf(w.z, dout[k], g[2]);
+                            g[3] = fmaf(w.w, dout[k], g[3]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * q + j;
+                        const float hv = H2[t][r];
+                        const float dz = g[j] * (1.0f - hv * hv);
+                        gb2[t][r] += dz;
+                        stgA[c * STG_LD + 32 * t + rho(r, h)] = dz;
+                        stgB[c * STG_LD + 32 * t + rho(r, h)] = H1[t][r];
+                    }
+                }
+            }
+            __syncthreads();  // buffers of this tile are complete
+        }
+    } else {
+        // ======================================================================= backward wave
+        for (int it = 0; it < n_iter; ++it) {
+            const int64_t tile = tile0 + (int64_t)it * tstride;
+            const int64_t m0 = tile * TILE_M;
+            // xp[s][jt] = X_aug[sample 2s+h][input 32*jt + c] for the layer-1 wgrad, fetched before
+            // the barriers so that it is long there when needed (lines the partner loaded a tile ago)
+            float xp[16][JT];
+            {
+                const bool full = m0 + TILE_M <= a.n;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const int in = 32 * jt + c;
+                    const float fill = in == S ? 1.0f : 0.0f;
+                    const int inc = min(in, S - 1);
+                    if (full) {
+                        const float* p0 = a.states + (m0 + h) * S + inc;
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            const float v = p0[(int64_t)(2 * s) * S];
+                            xp[s][jt] = in < S ? v : fill;
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            const int64_t gm = min(m0 + 2 * s + h, a.n - 1);
+                            const float v = a.states[gm * S + inc];
+                            xp[s][jt] = in < S ? v : fill;
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // (forward wave: previous buffers may be overwritten)
+            __syncthreads();  // buffers of this tile are complete
+
+            // ---------------- dgrad of layer 2: dH1^T[in, m] = sum_out W2[out, in] dZ2[m, out]
+            f32x16 d0 = {0}, d1 = {0};
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int k = 2 * s + h;  // output unit of layer 2
+                const float b = stgA[c * STG_LD + k];
+                d0 = mfma32(L.w2n[k * HID + c], b, d0);
+                d1 = mfma32(L.w2n[k * HID + 32 + c], b, d1);
+            }
+            // ---------------- through tanh: dZ1 = dH1 * (1 - H1^2); transposed into stgC
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float h0 = stgB[c * STG_LD + rho(r, h)];
+                const float h1 = stgB[c * STG_LD + 32 + rho(r, h)];
+                stgC[c * STG_LD + rho(r, h)] = d0[r] * (1.0f - h0 * h0);
+                stgC[c * STG_LD + 32 + rho(r, h)] = d1[r] * (1.0f - h1 * h1);
+            }
+            // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int mm = 2 * s + h;
-                const float av = c < AOUT ? stgD[mm * STG_D + c] : 0.f;
-                gW3[0] = mfma32(av, stgC[mm * STG_LD + c], gW3[0]);
-                gW3[1] = mfma32(av, stgC[mm * STG_LD + 32 + c], gW3[1]);
+                const float a0 = stgA[mm * STG_LD + c];
+                const float a1 = stgA[mm * STG_LD + 32 + c];
+                const float b0 = stgB[mm * STG_LD + c];
+                const float b1 = stgB[mm * STG_LD + 32 + c];
+                gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
+                gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
+                gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
+                gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
             }
-        }
-
-        STAMP(5)
-        // ---------------- operands of the layer-2 wgrad (consumed during the next tile's forward)
+            // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int s = 0; s < 16; ++s) {
+                const int mm = 2 * s + h;
+                const float a0 = stgC[mm * STG_LD + c];
+                const float a1 = stgC[mm * STG_LD + 32 + c];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                stgA[c * STG_LD + 32 * t + rho(r, h)] = dZ2[t][r];
-                stgB[c * STG_LD + 32 * t + rho(r, h)] = H1[t][r];
+                for (int jt = 0; jt < JT; ++jt) {
+                    gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
+                    gW1[1][jt] = mfma32(a1, xp[s][jt], gW1[1][jt]);
+                }
             }
-
-        STAMP(6)
-        // ---------------- dgrad of layer 2: dH1^T = W2^T dZ2^T, then through tanh
-        f32x16 dZ1[2];
-        dZ1[0] = 0.f;
-        dZ1[1] = 0.f;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = 32 * st + rho(r, h);  // output unit of layer 2
-                const float b = dZ2[st][r];
-                dZ1[0] = mfma32(L.w2n[k * HID + c], b, dZ1[0]);
-                dZ1[1] = mfma32(L.w2n[k * HID + 32 + c], b, dZ1[1]);
-            }
-        }
-        STAMP(7)
-        dZ1[0] = dZ1[0] * (1.0f - H1[0] * H1[0]);
-        dZ1[1] = dZ1[1] * (1.0f - H1[1] * H1[1]);
-        // ---------------- operand of the layer-1 wgrad (ditto)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stgC[c * STG_LD + 32 * t + rho(r, h)] = dZ1[t][r];
-        STAMP(8)
-    }
-    STAMP_START
-
-    // ---------------- the last tile's pending wgrads
-    load_xp();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        wgrad2(s, 0, 0);
-        wgrad2(s, 0, 1);
-        wgrad2(s, 1, 0);
-        wgrad2(s, 1, 1);
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            wgrad1(s, 0, jt);
-            wgrad1(s, 1, jt);
         }
     }
 
-    STAMP(9)
+    __syncthreads();  // every wave is done with the transposition buffers
     // ---------------- reduce lanes -> wave -> workgroup -> global partial row
-    // Per-lane partial sums (one per sample column) are summed over the 32 samples through the
-    // wave's own LDS space: written as [register][lane], read back as 32 consecutive floats per
-    // hidden unit, lane u ending up with unit u's total.  Fixed order, no cross-lane instructions.
-    auto colsum = [&](const f32x16 (&v)[2]) -> float {
+    float db2_u = 0.f;                 // d/d b2[lane]
+    float dw3_u[L3_VALU ? AOUT : 1];   // d/d W3[k][lane] on the VALU path
+    if (is_fwd) {
+        db2_u = colsum(stgA, gb2, lane);
+        if constexpr (L3_VALU) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(stgA, gW3v[k], lane);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stgA[(16 * t + r) * STG_LD + lane] = v[t][r];
-        const int q = lane & 31;
-        const float* src = stgA + (16 * (lane >> 5) + (q & 3) + 4 * (q >> 3)) * STG_LD + 32 * ((q >> 2) & 1);
-        float acc = 0.f;
+        for (int k = 0; k < AOUT; ++k) {
+            float v = gb3[k];
 #pragma unroll
-        for (int cc = 0; cc < 32; ++cc) acc += src[cc];
-        return acc;
-    };
-    const float db2_u = colsum(gb2);  // d/d b2[lane]
-    float dw3_u[L3_VALU ? AOUT : 1];  // d/d W3[k][lane] on the VALU path
-    if constexpr (L3_VALU) {
+            for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+            gb3[k] = v;
+        }
 #pragma unroll
-        for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(gW3v[k]);
+        for (int off = 1; off < 64; off <<= 1) loss_acc += __shfl_xor(loss_acc, off);
     }
-#pragma unroll
-    for (int k = 0; k < AOUT; ++k) {
-        float v = gb3[k];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-        gb3[k] = v;
-    }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) loss_acc += __shfl_xor(loss_acc, off);
-
-    __syncthreads();  // every wave is done with its staging buffers
+    __syncthreads();
     float* red = stg;  // [P.n + 1], indices relative to this MLP's first parameter
     const int o_w1 = P.w1 - base, o_b1 = P.b1 - base, o_w2 = P.w2 - base, o_b2 = P.b2 - base,
               o_w3 = P.w3 - base, o_b3 = P.b3 - base, o_loss = P.n;
-    for (int w = 0; w < FB_WAVES; ++w) {
-        if (wave == w) {
+    // step w: forward wave w and backward wave w+4 add their (disjoint) shares
+    for (int w = 0; w < FB_PAIRS; ++w) {
+        if (pair == w) {
             const bool first = w == 0;
 #define RED_PUT(idx, val) { const int _i = (idx); red[_i] = first ? (val) : red[_i] + (val); }
+            if (!is_fwd) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int out = 32 * i + rho(r, h);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) RED_PUT(o_w2 + out * HID + 32 * j + c, gW2[i][j][r]);
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) {
-                        const int in = 32 * jt + c;
-                        if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
-                        else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
-                    }
-                }
-            RED_PUT(o_b2 + lane, db2_u);
-            if constexpr (L3_VALU) {
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k)
-                    if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int act_row = rho(r, h);
-                        if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
-                    }
-            }
-            if (lane == 0) {
+                        const int out = 32 * i + rho(r, h);
 #pragma unroll
-                for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
-                const float lv = HEAD == HEAD_VALUE ? (float)(0.5 * loss_acc * (double)a.inv_n)
-                                                    : (float)(loss_acc * (double)a.inv_n);
-                RED_PUT(o_loss, lv);
+                        for (int j = 0; j < 2; ++j) RED_PUT(o_w2 + out * HID + 32 * j + c, gW2[i][j][r]);
+#pragma unroll
+                        for (int jt = 0; jt < JT; ++jt) {
+                            const int in = 32 * jt + c;
+                            if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
+                            else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
+                        }
+                    }
+            } else {
+                RED_PUT(o_b2 + lane, db2_u);
+                if constexpr (L3_VALU) {
+#pragma unroll
+                    for (int k = 0; k < AOUT; ++k)
+                        if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int act_row = rho(r, h);
+                            if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
+                        }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
+                    const float lv = HEAD == HEAD_VALUE ? (float)(0.5 * loss_acc * (double)a.inv_n)
+                                                        : (float)(loss_acc * (double)a.inv_n);
+                    RED_PUT(o_loss, lv);
+                }
             }
 #undef RED_PUT
         }
@@ -484,17 +479,10 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     float* dst = HEAD == HEAD_VALUE ? a.partial_critic + (size_t)wg * a.stride_critic
                                     : a.partial_actor + (size_t)wg * a.stride_actor;
     for (int i = threadIdx.x; i < P.n + 1; i += FB_THREADS) dst[i] = red[i];
-    STAMP(10)
-#ifdef PPO_PHASE_STAMPS
-    if (a.stamps && lane == 0) {
-        unsigned long long* row = a.stamps + ((size_t)blockIdx.x * FB_WAVES + wave) * 16;
-        for (int i = 0; i < 12; ++i) row[i] = st_acc[i];
-    }
-#endif
 }
 
 template <bool CONT, int AMAX, int JT>
-__global__ __launch_bounds__(FB_THREADS, 1) void fwdbwd_kernel(const FwdBwdArgs a) {
+__global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs a) {
     extern __shared__ __align__(16) float smem[];
     if ((blockIdx.x & 1) == 0)
         run_role<CONT ? HEAD_GAUSSIAN : HEAD_CATEGORICAL, AMAX, JT>(a, smem);
@@ -502,24 +490,33 @@ __global__ __launch_bounds__(FB_THREADS, 1) void fwdbwd_kernel(const FwdBwdArgs 
         run_role<HEAD_VALUE, 1, JT>(a, smem);
 }
 
-// grad[p] = sum over the role's workgroups (fixed order, fp64 accumulate).
+// grad[p] = sum over the role's workgroups (fixed order, fp64 accumulate).  One block per 64
+// parameters: 4 row groups x 64 columns, the 4 partial sums combined in fixed order through LDS.
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial_actor,
                                                           const float* __restrict__ partial_critic,
                                                           int stride_actor, int stride_critic,
                                                           int n_actor, int n_critic, int rows,
                                                           float* __restrict__ grad) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double part[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
     const int P = n_actor + n_critic;
-    if (i >= P + 2) return;
-    const float* src;
-    int stride;
-    if (i < n_actor) { src = partial_actor + i; stride = stride_actor; }
-    else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; }
-    else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; }
-    else { src = partial_critic + n_critic; stride = stride_critic; }
     double s = 0.0;
-    for (int g = 0; g < rows; ++g) s += (double)src[(size_t)g * stride];
-    grad[i] = (float)s;
+    if (i < P + 2) {
+        const float* src;
+        int stride;
+        if (i < n_actor) { src = partial_actor + i; stride = stride_actor; }
+        else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; }
+        else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; }
+        else { src = partial_critic + n_critic; stride = stride_critic; }
+        const int per = (rows + 3) / 4;
+        const int lo = grp * per, hi = min(rows, lo + per);
+#pragma unroll 8
+        for (int g = lo; g < hi; ++g) s += (double)src[(size_t)g * stride];
+    }
+    part[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < P + 2) grad[i] = (float)(((part[0][col] + part[1][col]) + part[2][col]) + part[3][col]);
 }
 
 // torch/optim/adam.py:457-547, single-tensor path; operation order kept (no contraction).
@@ -573,12 +570,13 @@ extern "C" int64_t ppo_param_count(int state_dim, int action_dim, int64_t* n_act
 
 static size_t fwdbwd_lds_bytes(int S, int amax) {
     const int net = round4(net_lds_floats(S, amax, true));
-    return (size_t)(net + FB_WAVES * STG_WAVE_FLOATS) * sizeof(float);
+    return (size_t)(net + FB_PAIRS * STG_PAIR_FLOATS) * sizeof(float);
 }
 
 template <bool CONT, int AMAX, int JT>
 static int launch_fwdbwd(const FwdBwdArgs& a, hipStream_t st) {
     const size_t lds = fwdbwd_lds_bytes(a.S, AMAX);
+    if (lds > 160 * 1024) return PPO_E_UNSUPPORTED;
     static size_t configured = 0;
     if (lds > configured) {
         const hipError_t e = hipFuncSetAttribute((const void*)fwdbwd_kernel<CONT, AMAX, JT>,
@@ -605,11 +603,6 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
         return PPO_E_UNSUPPORTED;
     if (!workspace || workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
     FwdBwdArgs a;
-#ifdef PPO_PHASE_STAMPS
-    a.stamps = g_stamp_buf;
-#else
-    a.stamps = nullptr;
-#endif
     a.params = params;
     a.S = state_dim;
     a.A = action_dim;
@@ -663,8 +656,8 @@ extern "C" int ppo_grad_reduce(int state_dim, int action_dim, const void* worksp
     const float* pc = (const float*)((const char*)workspace +
                                      align_up((size_t)(FB_GRID / 2) * sa * sizeof(float), 256));
     const int total = na + nc + 2;
-    grad_reduce_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(pa, pc, sa, sc, na, nc,
-                                                                            FB_GRID / 2, grad_out);
+    grad_reduce_kernel<<<(total + 63) / 64, 256, 0, (hipStream_t)stream>>>(pa, pc, sa, sc, na, nc,
+                                                                          FB_GRID / 2, grad_out);
     return (int)hipGetLastError();
 }
 
