@@ -147,40 +147,36 @@ __device__ __forceinline__ float colsum(float* buf, const f32x16 (&v)[2], int la
     return acc;
 }
 
+// Everything one wave needs to know about its place in the workgroup.
+struct WaveCtx {
+    NetLds L;
+    NetLayout P;
+    int base;          // first parameter of this MLP in the flat vector
+    int S, A;
+    int pair, lane, h, c;
+    float* stgA;       // dZ2   [32][STG_LD]   forward -> backward
+    float* stgB;       // H1    [32][STG_LD]   forward -> backward (H2 while the MFMA output wgrad runs)
+    float* stgC;       // dZ1   [32][STG_LD]   private to the backward wave
+    float* stgD;       // dout  [32][STG_D]
+    float* red;        // [P.n + 1] workgroup reduction buffer (aliases the transposition space)
+    int64_t tile0, tstride, n_tiles;
+    int n_iter;        // same for every wave of the grid: the barriers match
+};
+
+#define RED_PUT(idx, val) { const int _i = (idx); ctx.red[_i] = first ? (val) : ctx.red[_i] + (val); }
+
+// ------------------------------------------------------------------------------ forward wave
 template <int HEAD, int AOUT, int JT>
-__device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
-    const int S = a.S;
-    const int A = HEAD == HEAD_VALUE ? 1 : a.A;
-    const NetLayout P = HEAD == HEAD_VALUE ? net_layout(n_actor_params(S, a.A), S, 1)
-                                           : net_layout(0, S, a.A);
-    const int base = HEAD == HEAD_VALUE ? n_actor_params(S, a.A) : 0;
-    const int wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int pair = wave & (FB_PAIRS - 1);
-    const bool is_fwd = wave < FB_PAIRS;
-
-    const NetLds L = carve_net_lds(smem, S, AOUT, true);
-    float* stg = smem + round4(net_lds_floats(S, AOUT, true));
-    // per-pair transposition buffers [32 samples][STG_LD]: A = dZ2, B = H1 (H2 while the output
-    // layer's MFMA wgrad runs), C = dZ1 (private to the backward wave), D = dout [32][STG_D]
-    float* stgA = stg + pair * STG_PAIR_FLOATS;
-    float* stgB = stgA + TILE_M * STG_LD;
-    float* stgC = stgB + TILE_M * STG_LD;
-    float* stgD = stgC + TILE_M * STG_LD;
-    fill_net_lds(L, a.params, P, S, A, AOUT, true);
-    __syncthreads();
-
-    const int64_t n_tiles = (a.n + TILE_M - 1) / TILE_M;
-    const int64_t tstride = (int64_t)nwg * FB_PAIRS;
-    const int64_t tile0 = (int64_t)wg * FB_PAIRS + pair;
-    const int n_iter = (int)((n_tiles + tstride - 1) / tstride);  // same for every wave: barriers match
-    const int ks1 = ks1_of(S);
+__device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx) {
+    const NetLds& L = ctx.L;
+    const int S = ctx.S, A = ctx.A, lane = ctx.lane, h = ctx.h, c = ctx.c;
+    float* const stgA = ctx.stgA;
+    float* const stgB = ctx.stgB;
+    float* const stgD = ctx.stgD;
     constexpr bool L3_VALU = AOUT <= 2;  // output-layer wgrad on the VALU (A*32 FMAs per tile)
+    constexpr int KS1MAX = 16 * JT;
 
-    // accumulators kept across all tiles (only the role that owns them touches them)
-    f32x16 gW2[2][2], gW1[2][JT];                             // backward wave
-    f32x16 gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];       // forward wave
+    f32x16 gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];
     float gb3[AOUT];
     double loss_acc = 0.0;
 #pragma unroll
@@ -189,296 +185,340 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
         gb2[i] = 0.f;
 #pragma unroll
         for (int k = 0; k < (L3_VALU ? AOUT : 1); ++k) gW3v[k][i] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < AOUT; ++k) gb3[k] = 0.f;
+
+    // xf[s] = X_aug[this lane's sample][input 2s+h] (1 at input S, 0 beyond), fetched one tile
+    // ahead.  Row pointer + constant offsets: one instruction per load.
+    float xf[KS1MAX];
+    auto load_xf = [&](int64_t t_m0, int half_s) {
+        const int64_t mi = min(t_m0 + c, a.n - 1);
+        const float* row = a.states + mi * S + h;
+#pragma unroll
+        for (int s = 0; s < KS1MAX; ++s) {
+            if (s < half_s) xf[s] = row[2 * s];
+            else if (s == half_s) xf[s] = (S & 1) ? (h == 0 ? row[2 * s] : 1.0f) : (h == 0 ? 1.0f : 0.0f);
+        }
+    };
+    load_xf(min(ctx.tile0, ctx.n_tiles - 1) * TILE_M, S >> 1);
+    for (int it = 0; it < ctx.n_iter; ++it) {
+        const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
+        const int64_t m = tile * TILE_M + c;
+        const bool valid = m < a.n;
+        // loop-invariant, but kept opaque so that the 16 step guards are re-derived with one
+        // scalar compare each instead of living in (spilled) scalar registers
+        int ks1 = ks1_of(S), half_s = S >> 1;
+        asm volatile("" : "+s"(ks1), "+s"(half_s));
+
+        // ---------------- layer 1 (bias rides as the ones column of X)
+        f32x16 H1[2], H2[2];
+        {
+            f32x16 z0 = {0}, z1 = {0};
+#pragma unroll
+            for (int s = 0; s < KS1MAX; ++s) {
+                if (s < ks1) {
+                    const int k = 2 * s + h;
+                    z0 = mfma32(L.w1t[k * HID + c], xf[s], z0);
+                    z1 = mfma32(L.w1t[k * HID + 32 + c], xf[s], z1);
+                }
+            }
+            load_xf(min(tile + ctx.tstride, ctx.n_tiles - 1) * TILE_M, half_s);  // next tile's
+            H1[0] = tanh16_prescaled(z0);
+            H1[1] = tanh16_prescaled(z1);
+        }
+        // ---------------- layer 2
+        {
+            f32x16 y0, y1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] = L.b2[rho(r, h)];
+                y1[r] = L.b2[32 + rho(r, h)];
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = 32 * st + rho(r, h);
+                    const float b = H1[st][r];
+                    y0 = mfma32(L.w2t[k * HID + c], b, y0);
+                    y1 = mfma32(L.w2t[k * HID + 32 + c], b, y1);
+                }
+            }
+            H2[0] = tanh16_prescaled(y0);
+            H2[1] = tanh16_prescaled(y1);
+        }
+        float o[AOUT];
+        out_layer<AOUT>(L, A, H2, h, o);
+
+        // ---------------- head, loss, gradient w.r.t. the pre-head outputs
+        float dout[AOUT];
+        head_loss_grad<HEAD, AOUT>(a, A, o, m, valid, h == 0, dout, loss_acc);
+        if (h == 0) {
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) gb3[k] += dout[k];
+        }
+        if constexpr (L3_VALU) {  // dW3[k, u] += dout[m, k] * H2[m, u], per-lane partials
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) {
+                gW3v[k][0] += dout[k] * H2[0];
+                gW3v[k][1] += dout[k] * H2[1];
+            }
+        }
+
+        __syncthreads();  // the partner has finished reading the previous tile's buffers
+
+        if constexpr (!L3_VALU) {
+            // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u], H2
+            // transposed through stgB before H1 takes its place
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
+            if (h == 0) {
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) stgD[c * STG_D + k] = dout[k];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int mm = 2 * s + h;
+                const float av = c < AOUT ? stgD[mm * STG_D + c] : 0.f;
+                gW3[0] = mfma32(av, stgB[mm * STG_LD + c], gW3[0]);
+                gW3[1] = mfma32(av, stgB[mm * STG_LD + 32 + c], gW3[1]);
+            }
+        }
+        // ---------------- output layer backward: dZ2 = (W3^T dout) * (1 - H2^2), handed over
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) {
+                    if (k < A) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[k * HID + 32 * t + 8 * q + 4 * h]);
+                        g[0] = fmaf(w.x, dout[k], g[0]);
+                        g[1] = fmaf(w.y, dout[k], g[1]);
+                        g[2] = fmaf(w.z, dout[k], g[2]);
+                        g[3] = fmaf(w.w, dout[k], g[3]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * q + j;
+                    const float hv = H2[t][r];
+                    const float dz = g[j] * (1.0f - hv * hv);
+                    gb2[t][r] += dz;
+                    stgA[c * STG_LD + 32 * t + rho(r, h)] = dz;
+                    stgB[c * STG_LD + 32 * t + rho(r, h)] = H1[t][r];
+                }
+            }
+        }
+        __syncthreads();  // buffers of this tile are complete
+    }
+
+    __syncthreads();  // every wave is done with the transposition buffers
+    // per-lane partials -> per-unit sums through this pair's own LDS space
+    const float db2_u = colsum(stgA, gb2, lane);  // d/d b2[lane]
+    float dw3_u[L3_VALU ? AOUT : 1];              // d/d W3[k][lane] on the VALU path
+    if constexpr (L3_VALU) {
+#pragma unroll
+        for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(stgA, gW3v[k], lane);
+    }
+#pragma unroll
+    for (int k = 0; k < AOUT; ++k) {
+        float v = gb3[k];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        gb3[k] = v;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) loss_acc += __shfl_xor(loss_acc, off);
+    __syncthreads();
+    const int o_b2 = ctx.P.b2 - ctx.base, o_w3 = ctx.P.w3 - ctx.base, o_b3 = ctx.P.b3 - ctx.base,
+              o_loss = ctx.P.n;
+    for (int w = 0; w < FB_PAIRS; ++w) {
+        if (ctx.pair == w) {
+            const bool first = w == 0;
+            RED_PUT(o_b2 + lane, db2_u);
+            if constexpr (L3_VALU) {
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k)
+                    if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int act_row = rho(r, h);
+                        if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
+                    }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
+                const float lv = HEAD == HEAD_VALUE ? (float)(0.5 * loss_acc * (double)a.inv_n)
+                                                    : (float)(loss_acc * (double)a.inv_n);
+                RED_PUT(o_loss, lv);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------ backward wave
+template <int JT>
+__device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx) {
+    const NetLds& L = ctx.L;
+    const int S = ctx.S, h = ctx.h, c = ctx.c;
+    float* const stgA = ctx.stgA;
+    float* const stgB = ctx.stgB;
+    float* const stgC = ctx.stgC;
+    f32x16 gW2[2][2], gW1[2][JT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) gW2[i][j] = 0.f;
 #pragma unroll
         for (int j = 0; j < JT; ++j) gW1[i][j] = 0.f;
     }
+    for (int it = 0; it < ctx.n_iter; ++it) {
+        const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
+        const int64_t m0 = tile * TILE_M;
+        // xp[s][jt] = X_aug[sample 2s+h][input 32*jt + c] for the layer-1 wgrad, fetched before
+        // the barriers so that it is long there when needed (lines the partner loaded a tile ago)
+        float xp[16][JT];
+        {
+            const bool full = m0 + TILE_M <= a.n;
 #pragma unroll
-    for (int k = 0; k < AOUT; ++k) gb3[k] = 0.f;
-
-    if (is_fwd) {
-        // ======================================================================= forward wave
-        // xf[s] = X_aug[this lane's sample][input 2s+h] (1 at input S, 0 beyond), fetched one tile
-        // ahead.  Row pointer + constant offsets: one instruction per load.
-        constexpr int KS1MAX = 16 * JT;
-        float xf[KS1MAX];
-        const int half_s = S >> 1;  // steps below this one read two real inputs
-        auto load_xf = [&](int64_t t_m0) {
-            const int64_t mi = min(t_m0 + c, a.n - 1);
-            const float* row = a.states + mi * S + h;
+            for (int jt = 0; jt < JT; ++jt) {
+                const int in = 32 * jt + c;
+                const float fill = in == S ? 1.0f : 0.0f;
+                const int inc = min(in, S - 1);
+                if (full) {
+                    const float* p0 = a.states + (m0 + h) * S + inc;
 #pragma unroll
-            for (int s = 0; s < KS1MAX; ++s) {
-                if (s < half_s) xf[s] = row[2 * s];
-                else if (s == half_s) xf[s] = (S & 1) ? (h == 0 ? row[2 * s] : 1.0f) : (h == 0 ? 1.0f : 0.0f);
-            }
-        };
-        load_xf(min(tile0, n_tiles - 1) * TILE_M);
-        for (int it = 0; it < n_iter; ++it) {
-            const int64_t tile = tile0 + (int64_t)it * tstride;
-            const int64_t m0 = tile * TILE_M;
-            const int64_t m = m0 + c;
-            const bool valid = m < a.n;
-
-            // ---------------- layer 1 (bias rides as the ones column of X)
-            f32x16 H1[2], H2[2];
-            {
-                f32x16 z0 = {0}, z1 = {0};
-#pragma unroll
-                for (int s = 0; s < KS1MAX; ++s) {
-                    if (s < ks1) {
-                        const int k = 2 * s + h;
-                        z0 = mfma32(L.w1t[k * HID + c], xf[s], z0);
-                        z1 = mfma32(L.w1t[k * HID + 32 + c], xf[s], z1);
+                    for (int s = 0; s < 16; ++s) {
+                        const float v = p0[(int64_t)(2 * s) * S];
+                        xp[s][jt] = in < S ? v : fill;
                     }
-                }
-                load_xf(min(tile + tstride, n_tiles - 1) * TILE_M);  // next tile's, in flight all tile long
-                H1[0] = tanh16_prescaled(z0);
-                H1[1] = tanh16_prescaled(z1);
-            }
-            // ---------------- layer 2
-            {
-                f32x16 y0, y1;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    y0[r] = L.b2[rho(r, h)];
-                    y1[r] = L.b2[32 + rho(r, h)];
-                }
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int k = 32 * st + rho(r, h);
-                        const float b = H1[st][r];
-                        y0 = mfma32(L.w2t[k * HID + c], b, y0);
-                        y1 = mfma32(L.w2t[k * HID + 32 + c], b, y1);
-                    }
-                }
-                H2[0] = tanh16_prescaled(y0);
-                H2[1] = tanh16_prescaled(y1);
-            }
-            float o[AOUT];
-            out_layer<AOUT>(L, A, H2, h, o);
-
-            // ---------------- head, loss, gradient w.r.t. the pre-head outputs
-            float dout[AOUT];
-            head_loss_grad<HEAD, AOUT>(a, A, o, m, valid, h == 0, dout, loss_acc);
-            if (h == 0) {
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k) gb3[k] += dout[k];
-            }
-            if constexpr (L3_VALU) {  // dW3[k, u] += dout[m, k] * H2[m, u], per-lane partials
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k) {
-                    gW3v[k][0] += dout[k] * H2[0];
-                    gW3v[k][1] += dout[k] * H2[1];
-                }
-            }
-
-            __syncthreads();  // the partner has finished reading the previous tile's buffers
-
-            if constexpr (!L3_VALU) {
-                // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u], H2
-                // transposed through stgB before H1 takes its place
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
-                if (h == 0) {
-#pragma unroll
-                    for (int k = 0; k < AOUT; ++k) stgD[c * STG_D + k] = dout[k];
-                }
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int mm = 2 * s + h;
-                    const float av = c < AOUT ? stgD[mm * STG_D + c] : 0.f;
-                    gW3[0] = mfma32(av, stgB[mm * STG_LD + c], gW3[0]);
-                    gW3[1] = mfma32(av, stgB[mm * STG_LD + 32 + c], gW3[1]);
-                }
-            }
-            // ---------------- output layer backward: dZ2 = (W3^T dout) * (1 - H2^2), handed over
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float g[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < AOUT; ++k) {
-                        if (k < A) {
-                            const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[k * HID + 32 * t + 8 * q + 4 * h]);
-                            g[0] = fmaf(w.x, dout[k], g[0]);
-                            g[1] = fmaf(w.y, dout[k], g[1]);
-                            g[2] = fmaf(w.z, dout[k], g[2]);
-                            g[3] = fmaf(w.w, dout[k], g[3]);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = 4 * q + j;
-                        const float hv = H2[t][r];
-                        const float dz = g[j] * (1.0f - hv * hv);
-                        gb2[t][r] += dz;
-                        stgA[c * STG_LD + 32 * t + rho(r, h)] = dz;
-                        stgB[c * STG_LD + 32 * t + rho(r, h)] = H1[t][r];
+                    for (int s = 0; s < 16; ++s) {
+                        const int64_t gm = min(m0 + 2 * s + h, a.n - 1);
+                        const float v = a.states[gm * S + inc];
+                        xp[s][jt] = in < S ? v : fill;
                     }
                 }
             }
-            __syncthreads();  // buffers of this tile are complete
         }
-    } else {
-        // ======================================================================= backward wave
-        for (int it = 0; it < n_iter; ++it) {
-            const int64_t tile = tile0 + (int64_t)it * tstride;
-            const int64_t m0 = tile * TILE_M;
-            // xp[s][jt] = X_aug[sample 2s+h][input 32*jt + c] for the layer-1 wgrad, fetched before
-            // the barriers so that it is long there when needed (lines the partner loaded a tile ago)
-            float xp[16][JT];
-            {
-                const bool full = m0 + TILE_M <= a.n;
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    const int in = 32 * jt + c;
-                    const float fill = in == S ? 1.0f : 0.0f;
-                    const int inc = min(in, S - 1);
-                    if (full) {
-                        const float* p0 = a.states + (m0 + h) * S + inc;
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) {
-                            const float v = p0[(int64_t)(2 * s) * S];
-                            xp[s][jt] = in < S ? v : fill;
-                        }
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) {
-                            const int64_t gm = min(m0 + 2 * s + h, a.n - 1);
-                            const float v = a.states[gm * S + inc];
-                            xp[s][jt] = in < S ? v : fill;
-                        }
-                    }
-                }
-            }
-            __syncthreads();  // (forward wave: previous buffers may be overwritten)
-            __syncthreads();  // buffers of this tile are complete
+        __syncthreads();  // (forward wave: previous buffers may be overwritten)
+        __syncthreads();  // buffers of this tile are complete
 
-            // ---------------- dgrad of layer 2: dH1^T[in, m] = sum_out W2[out, in] dZ2[m, out]
-            f32x16 d0 = {0}, d1 = {0};
+        // ---------------- dgrad of layer 2: dH1^T[in, m] = sum_out W2[out, in] dZ2[m, out]
+        f32x16 d0 = {0}, d1 = {0};
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const int k = 2 * s + h;  // output unit of layer 2
-                const float b = stgA[c * STG_LD + k];
-                d0 = mfma32(L.w2n[k * HID + c], b, d0);
-                d1 = mfma32(L.w2n[k * HID + 32 + c], b, d1);
-            }
-            // ---------------- through tanh: dZ1 = dH1 * (1 - H1^2); transposed into stgC
+        for (int s = 0; s < 32; ++s) {
+            const int k = 2 * s + h;  // output unit of layer 2
+            const float b = stgA[c * STG_LD + k];
+            d0 = mfma32(L.w2n[k * HID + c], b, d0);
+            d1 = mfma32(L.w2n[k * HID + 32 + c], b, d1);
+        }
+        // ---------------- through tanh: dZ1 = dH1 * (1 - H1^2); transposed into stgC
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float h0 = stgB[c * STG_LD + rho(r, h)];
-                const float h1 = stgB[c * STG_LD + 32 + rho(r, h)];
-                stgC[c * STG_LD + rho(r, h)] = d0[r] * (1.0f - h0 * h0);
-                stgC[c * STG_LD + 32 + rho(r, h)] = d1[r] * (1.0f - h1 * h1);
-            }
-            // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
+        for (int r = 0; r < 16; ++r) {
+            const float h0 = stgB[c * STG_LD + rho(r, h)];
+            const float h1 = stgB[c * STG_LD + 32 + rho(r, h)];
+            stgC[c * STG_LD + rho(r, h)] = d0[r] * (1.0f - h0 * h0);
+            stgC[c * STG_LD + 32 + rho(r, h)] = d1[r] * (1.0f - h1 * h1);
+        }
+        // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int mm = 2 * s + h;
-                const float a0 = stgA[mm * STG_LD + c];
-                const float a1 = stgA[mm * STG_LD + 32 + c];
-                const float b0 = stgB[mm * STG_LD + c];
-                const float b1 = stgB[mm * STG_LD + 32 + c];
-                gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
-                gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
-                gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
-                gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
-            }
-            // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
+        for (int s = 0; s < 16; ++s) {
+            const int mm = 2 * s + h;
+            const float a0 = stgA[mm * STG_LD + c];
+            const float a1 = stgA[mm * STG_LD + 32 + c];
+            const float b0 = stgB[mm * STG_LD + c];
+            const float b1 = stgB[mm * STG_LD + 32 + c];
+            gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
+            gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
+            gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
+            gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
+        }
+        // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int mm = 2 * s + h;
-                const float a0 = stgC[mm * STG_LD + c];
-                const float a1 = stgC[mm * STG_LD + 32 + c];
+        for (int s = 0; s < 16; ++s) {
+            const int mm = 2 * s + h;
+            const float a0 = stgC[mm * STG_LD + c];
+            const float a1 = stgC[mm * STG_LD + 32 + c];
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
-                    gW1[1][jt] = mfma32(a1, xp[s][jt], gW1[1][jt]);
-                }
+            for (int jt = 0; jt < JT; ++jt) {
+                gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
+                gW1[1][jt] = mfma32(a1, xp[s][jt], gW1[1][jt]);
             }
         }
     }
 
     __syncthreads();  // every wave is done with the transposition buffers
-    // ---------------- reduce lanes -> wave -> workgroup -> global partial row
-    float db2_u = 0.f;                 // d/d b2[lane]
-    float dw3_u[L3_VALU ? AOUT : 1];   // d/d W3[k][lane] on the VALU path
-    if (is_fwd) {
-        db2_u = colsum(stgA, gb2, lane);
-        if constexpr (L3_VALU) {
-#pragma unroll
-            for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(stgA, gW3v[k], lane);
-        }
-#pragma unroll
-        for (int k = 0; k < AOUT; ++k) {
-            float v = gb3[k];
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-            gb3[k] = v;
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) loss_acc += __shfl_xor(loss_acc, off);
-    }
-    __syncthreads();
-    float* red = stg;  // [P.n + 1], indices relative to this MLP's first parameter
-    const int o_w1 = P.w1 - base, o_b1 = P.b1 - base, o_w2 = P.w2 - base, o_b2 = P.b2 - base,
-              o_w3 = P.w3 - base, o_b3 = P.b3 - base, o_loss = P.n;
-    // step w: forward wave w and backward wave w+4 add their (disjoint) shares
+    __syncthreads();  // (forward waves: per-unit sums done)
+    const int o_w1 = ctx.P.w1 - ctx.base, o_b1 = ctx.P.b1 - ctx.base, o_w2 = ctx.P.w2 - ctx.base;
     for (int w = 0; w < FB_PAIRS; ++w) {
-        if (pair == w) {
+        if (ctx.pair == w) {
             const bool first = w == 0;
-#define RED_PUT(idx, val) { const int _i = (idx); red[_i] = first ? (val) : red[_i] + (val); }
-            if (!is_fwd) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int out = 32 * i + rho(r, h);
+                for (int r = 0; r < 16; ++r) {
+                    const int out = 32 * i + rho(r, h);
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) RED_PUT(o_w2 + out * HID + 32 * j + c, gW2[i][j][r]);
+                    for (int j = 0; j < 2; ++j) RED_PUT(o_w2 + out * HID + 32 * j + c, gW2[i][j][r]);
 #pragma unroll
-                        for (int jt = 0; jt < JT; ++jt) {
-                            const int in = 32 * jt + c;
-                            if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
-                            else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
-                        }
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const int in = 32 * jt + c;
+                        if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
+                        else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
                     }
-            } else {
-                RED_PUT(o_b2 + lane, db2_u);
-                if constexpr (L3_VALU) {
-#pragma unroll
-                    for (int k = 0; k < AOUT; ++k)
-                        if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int act_row = rho(r, h);
-                            if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
-                        }
                 }
-                if (lane == 0) {
-#pragma unroll
-                    for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
-                    const float lv = HEAD == HEAD_VALUE ? (float)(0.5 * loss_acc * (double)a.inv_n)
-                                                        : (float)(loss_acc * (double)a.inv_n);
-                    RED_PUT(o_loss, lv);
-                }
-            }
-#undef RED_PUT
         }
         __syncthreads();
     }
+}
+#undef RED_PUT
+
+template <int HEAD, int AOUT, int JT>
+__device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
+    WaveCtx ctx;
+    ctx.S = a.S;
+    ctx.A = HEAD == HEAD_VALUE ? 1 : a.A;
+    ctx.base = HEAD == HEAD_VALUE ? n_actor_params(a.S, a.A) : 0;
+    ctx.P = net_layout(ctx.base, a.S, ctx.A);
+    const int wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    ctx.lane = threadIdx.x & 63;
+    ctx.h = ctx.lane >> 5;
+    ctx.c = ctx.lane & 31;
+    ctx.pair = wave & (FB_PAIRS - 1);
+    ctx.L = carve_net_lds(smem, a.S, AOUT, true);
+    float* stg = smem + round4(net_lds_floats(a.S, AOUT, true));
+    ctx.stgA = stg + ctx.pair * STG_PAIR_FLOATS;
+    ctx.stgB = ctx.stgA + TILE_M * STG_LD;
+    ctx.stgC = ctx.stgB + TILE_M * STG_LD;
+    ctx.stgD = ctx.stgC + TILE_M * STG_LD;
+    ctx.red = stg;
+    ctx.n_tiles = (a.n + TILE_M - 1) / TILE_M;
+    ctx.tstride = (int64_t)nwg * FB_PAIRS;
+    ctx.tile0 = (int64_t)wg * FB_PAIRS + ctx.pair;
+    ctx.n_iter = (int)((ctx.n_tiles + ctx.tstride - 1) / ctx.tstride);
+    fill_net_lds(ctx.L, a.params, ctx.P, a.S, ctx.A, AOUT, true);
+    __syncthreads();
+
+    if (wave < FB_PAIRS) fwd_wave<HEAD, AOUT, JT>(a, ctx);
+    else bwd_wave<JT>(a, ctx);
+
+    // (both wave kinds end on the last barrier of the workgroup reduction)
     float* dst = HEAD == HEAD_VALUE ? a.partial_critic + (size_t)wg * a.stride_critic
                                     : a.partial_actor + (size_t)wg * a.stride_actor;
-    for (int i = threadIdx.x; i < P.n + 1; i += FB_THREADS) dst[i] = red[i];
+    for (int i = threadIdx.x; i < ctx.P.n + 1; i += FB_THREADS) dst[i] = ctx.red[i];
 }
 
 template <bool CONT, int AMAX, int JT>
