@@ -31,7 +31,24 @@
 #define STG_D 9                                        // row stride of the dout buffer
 #define STG_PAIR_FLOATS (3 * TILE_M * STG_LD + TILE_M * STG_D + 8)  // per-pair transposition space
 
+// Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
+// wave, written to a buffer registered with ppo_debug_set_stamps().  Never compiled into the product.
+#ifdef PPO_PHASE_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" void ppo_debug_set_stamps(void* p) { g_stamp_buf = (unsigned long long*)p; }
+#define STAMP_DECL unsigned long long st_acc[12] = {0}; unsigned long long st_prev = 0;
+#define STAMP_START { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[i] += _t - st_prev; st_prev = _t; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_FLUSH(a, wave) if ((a).stamps && (threadIdx.x & 63) == 0) { unsigned long long* row = (a).stamps + ((size_t)blockIdx.x * 8 + (wave)) * 16; for (int i = 0; i < 12; ++i) row[i] = st_acc[i]; }
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH(a, wave)
+#endif
+
 struct FwdBwdArgs {
+    unsigned long long* stamps;
     const float* params;
     int S, A;
     float action_var;
@@ -179,6 +196,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     f32x16 gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];
     float gb3[AOUT];
     double loss_acc = 0.0;
+    STAMP_DECL
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         gW3[i] = 0.f;
@@ -210,6 +228,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         // scalar compare each instead of living in (spilled) scalar registers
         int ks1 = ks1_of(S), half_s = S >> 1;
         asm volatile("" : "+s"(ks1), "+s"(half_s));
+        STAMP_START
 
         // ---------------- layer 1 (bias rides as the ones column of X)
         f32x16 H1[2], H2[2];
@@ -227,6 +246,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             H1[0] = tanh16_prescaled(z0);
             H1[1] = tanh16_prescaled(z1);
         }
+        STAMP(0)
         // ---------------- layer 2
         {
             f32x16 y0, y1;
@@ -248,6 +268,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             H2[0] = tanh16_prescaled(y0);
             H2[1] = tanh16_prescaled(y1);
         }
+        STAMP(1)
         float o[AOUT];
         out_layer<AOUT>(L, A, H2, h, o);
 
@@ -266,7 +287,9 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             }
         }
 
+        STAMP(2)
         __syncthreads();  // the partner has finished reading the previous tile's buffers
+        STAMP(3)
 
         if constexpr (!L3_VALU) {
             // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u], H2
@@ -314,8 +337,11 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                 }
             }
         }
+        STAMP(4)
         __syncthreads();  // buffers of this tile are complete
+        STAMP(5)
     }
+    STAMP_START
 
     __syncthreads();  // every wave is done with the transposition buffers
     // per-lane partials -> per-unit sums through this pair's own LDS space
@@ -364,6 +390,8 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         }
         __syncthreads();
     }
+    STAMP(6)
+    STAMP_FLUSH(a, ctx.pair)
 }
 
 // ------------------------------------------------------------------------------ backward wave
@@ -375,6 +403,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     float* const stgB = ctx.stgB;
     float* const stgC = ctx.stgC;
     f32x16 gW2[2][2], gW1[2][JT];
+    STAMP_DECL
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -385,6 +414,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     for (int it = 0; it < ctx.n_iter; ++it) {
         const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
         const int64_t m0 = tile * TILE_M;
+        STAMP_START
         // xp[s][jt] = X_aug[sample 2s+h][input 32*jt + c] for the layer-1 wgrad, fetched before
         // the barriers so that it is long there when needed (lines the partner loaded a tile ago)
         float xp[16][JT];
@@ -412,8 +442,11 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                 }
             }
         }
+        STAMP(0)
         __syncthreads();  // (forward wave: previous buffers may be overwritten)
+        STAMP(1)
         __syncthreads();  // buffers of this tile are complete
+        STAMP(2)
 
         // ---------------- dgrad of layer 2: dH1^T[in, m] = sum_out W2[out, in] dZ2[m, out]
         f32x16 d0 = {0}, d1 = {0};
@@ -424,6 +457,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             d0 = mfma32(L.w2n[k * HID + c], b, d0);
             d1 = mfma32(L.w2n[k * HID + 32 + c], b, d1);
         }
+        STAMP(3)
         // ---------------- through tanh: dZ1 = dH1 * (1 - H1^2); transposed into stgC
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -432,6 +466,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             stgC[c * STG_LD + rho(r, h)] = d0[r] * (1.0f - h0 * h0);
             stgC[c * STG_LD + 32 + rho(r, h)] = d1[r] * (1.0f - h1 * h1);
         }
+        STAMP(4)
         // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -445,6 +480,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
             gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
         }
+        STAMP(5)
         // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -482,6 +518,8 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         }
         __syncthreads();
     }
+    STAMP(7)
+    STAMP_FLUSH(a, FB_PAIRS + ctx.pair)
 }
 #undef RED_PUT
 
@@ -643,6 +681,11 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
         return PPO_E_UNSUPPORTED;
     if (!workspace || workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
     FwdBwdArgs a;
+#ifdef PPO_PHASE_STAMPS
+    a.stamps = g_stamp_buf;
+#else
+    a.stamps = nullptr;
+#endif
     a.params = params;
     a.S = state_dim;
     a.A = action_dim;

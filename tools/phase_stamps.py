@@ -36,18 +36,21 @@ for t in range(T):
     _lib.check(L.ppo_synth_env_step(xs.data_ptr(), rs.data_ptr(), ds.data_ptr(), N, S, cfg["reward_kind"],
                                     cfg["p_terminal"], t, T, 1234, _lib.stream_ptr()))
     agent.act_inplace(N)
-stamps = torch.zeros(1024 * 16, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(2048 * 16, dtype=torch.int64, device="cuda")
 ctypes.CDLL(LIB).ppo_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 agent.kernel_events = []
 agent.update()
 torch.cuda.synchronize()
 print("ms per launch:", [round(a.elapsed_time(b), 4) for a, b in agent.kernel_events])
-st = stamps.view(1024, 16).cpu().numpy().astype(float)
-names = ["L1 fwd + loads", "tanh1 || wgrad2(prev)", "L2 fwd", "tanh2 || wgrad1(prev)", "out layer + head",
-         "dZ2 + L3 wgrad", "stage dZ2,H1", "dgrad L2", "dZ1 + stage", "flush", "epilogue reduce"]
+st = stamps.view(256, 8, 16).cpu().numpy().astype(float)
+fwd_names = ["L1 + tanh", "L2 + tanh", "out layer + head + L3 wgrad", "WAIT barrier (partner done)",
+             "dZ2 + hand-off writes", "WAIT barrier (written)", "epilogue"]
+bwd_names = ["xp loads issue", "WAIT barrier (free)", "WAIT barrier (written)", "dgrad", "dZ1 + transpose",
+             "wgrad2", "wgrad1", "epilogue"]
 for role, sel in (("actor", slice(0, None, 2)), ("critic", slice(1, None, 2))):
-    rows = st.reshape(256, 4, 16)[sel].reshape(-1, 16)
-    tot = rows[:, :11].sum(1).mean()
-    print(f"{role}: mean cycles/wave {tot:.0f}")
-    for i, nme in enumerate(names):
-        print(f"   {nme:26s} {rows[:, i].mean():10.0f}  {100 * rows[:, i].mean() / tot:5.1f}%")
+    for kind, ws, names in (("forward wave", slice(0, 4), fwd_names), ("backward wave", slice(4, 8), bwd_names)):
+        rows = st[sel][:, ws].reshape(-1, 16)
+        tot = rows[:, :len(names)].sum(1).mean()
+        print(f"{role} {kind}: mean cycles/wave {tot:.0f} ({tot / 32:.0f} per tile)")
+        for i, nme in enumerate(names):
+            print(f"   {nme:30s} {rows[:, i].mean():10.0f}  {100 * rows[:, i].mean() / tot:5.1f}%  {rows[:, i].mean() / 32:7.0f}/tile")
