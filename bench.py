@@ -161,6 +161,14 @@ def main():
     p2 = time.perf_counter()
     phases = {"rollout_ms": (ph["rollout"] - p0) * 1e3, "update_ms": (p2 - ph["rollout"]) * 1e3}
 
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(args.config, {}).get("bytes_per_launch")
+        if args.n_envs or args.k_epochs:
+            traffic = None  # measured for the default shape only
+    except OSError:
+        pass
     if rank == 0:
         steps_total = N * T * world * args.steps
         flops_launch = flops_per_sample_epoch(S, A) * N * T
@@ -175,7 +183,7 @@ def main():
                        "state_dim": S, "action_dim": A, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "fwdbwd_kernel", "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": kern_ms, "launches_timed": len(events),
                          "flop_per_sample_epoch": flops_per_sample_epoch(S, A)},
             "phases": phases,

@@ -37,9 +37,9 @@ def merge_moments(moments):
     if not is_distributed():
         return moments
     world = td.get_world_size()
-    gathered = torch.empty(world * 3, dtype=moments.dtype, device=moments.device)
-    td.all_gather_into_tensor(gathered, moments.contiguous())
-    return merge_moments_list(gathered.view(world, 3)).contiguous()
+    parts = [torch.empty_like(moments) for _ in range(world)]
+    td.all_gather(parts, moments.contiguous())
+    return merge_moments_list(torch.stack(parts)).contiguous()
 
 
 def all_reduce_sum(t):

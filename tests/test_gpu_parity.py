@@ -353,6 +353,67 @@ def test_batched_update_equals_flat_with_row_end_terminals(eng):
     assert max(max_abs(got[k], P0[k]) for k in O.PARAM_KEYS) < TOL_PARAM
 
 
+# ------------------------------------------------------------------------------ data parallel
+def _dp_gpu_worker(rank, world, port, case, K, q):
+    import contextlib
+    import io
+    import torch.distributed as td
+    td.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from ppo_amd import ppo
+    d = load_case(case)
+    T = int(d["T"])
+    cut = (T * 2) // 5                                   # uneven shards
+    lo, hi = (0, cut) if rank == 0 else (cut, T)
+    cont = bool(d["continuous"])
+    agent = ppo.PPO(int(d["S"]), int(d["A"]), float(d["lr_actor"]), float(d["lr_critic"]),
+                    float(d["gamma"]), K, float(d["eps_clip"]), cont,
+                    float(d["action_std"]) if cont else None)
+    sd = {k: torch.from_numpy(v) for k, v in case_params(d).items()}
+    agent.policy.load_state_dict(sd)
+    agent.policy_old.load_state_dict(sd)
+    # a shard must end at an episode boundary of the flat sequence for its scan to be independent:
+    # scan the whole sequence with the oracle and hand each rank rewards that reproduce its slice
+    ret64 = O.returns_scan(d["rewards"], d["terminals"], float(d["gamma"]))
+    term = d["terminals"].copy()
+    rew = d["rewards"].copy()
+    if hi < T:                                            # carry entering this shard from the right
+        rew[hi - 1] = ret64[hi - 1]
+        term[hi - 1] = True
+    agent.buffer.load_rollout(d["states"][lo:hi], d["actions"][lo:hi], d["old_logprobs"][lo:hi],
+                              d["old_values"][lo:hi], rew[lo:hi], term[lo:hi])
+    agent.update()
+    torch.cuda.synchronize()
+    q.put((rank, agent.policy.flat.cpu().numpy(), agent.last_loss.cpu().numpy()))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["c2_lunarlander", "edge_std01"])
+def test_two_rank_update_equals_single_buffer(eng, case):
+    """Two processes (gloo rendezvous, both on this GPU) each own a shard of the rollout and run
+    the engine's real update(): merged moments + all-reduced gradients must reproduce the
+    reference's single-buffer result (golden) and leave identical parameters on both ranks."""
+    import torch.multiprocessing as mp
+    d = load_case(case)
+    K = int(d["K_list"][1])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, case, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=110) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1])          # replicas stay bit-identical
+    got = O.unflatten_params(res[0][1], int(d["S"]), int(d["A"]))
+    worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
+    assert worst < TOL_PARAM, worst
+    assert rel_err(res[0][2], d[f"K{K}/loss_mean_all"]) < 1e-4
+
+
 # ------------------------------------------------------------------------------ checkpoints / schedule
 def test_checkpoint_roundtrip(eng, tmp_path):
     ppo, _lib = eng
