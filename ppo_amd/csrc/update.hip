@@ -180,10 +180,14 @@ struct WaveCtx {
     int n_iter;        // same for every wave of the grid: the barriers match
 };
 
-#define RED_PUT(idx, val) { const int _i = (idx); ctx.red[_i] = first ? (val) : ctx.red[_i] + (val); }
+// Workgroup reduction: after the tile loop all of LDS is free; every pair owns a full
+// parameter-indexed array red[pair][P.n + 1] into which its two waves store their (disjoint) sums
+// with plain stores; one barrier later all threads add the four arrays in fixed order.
+#define RED_PUT(idx, val) { ctx.red[(idx)] = (val); }
 
 // ------------------------------------------------------------------------------ forward wave
-template <int HEAD, int AOUT, int JT>
+// L1 = shape class of layer 1: 0: S+1 <= 16, 1: S+1 <= 32, 2: S+1 <= 64
+template <int HEAD, int AOUT, int L1>
 __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx) {
     const NetLds& L = ctx.L;
     const int S = ctx.S, A = ctx.A, lane = ctx.lane, h = ctx.h, c = ctx.c;
@@ -191,7 +195,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     float* const stgB = ctx.stgB;
     float* const stgD = ctx.stgD;
     constexpr bool L3_VALU = AOUT <= 2;  // output-layer wgrad on the VALU (A*32 FMAs per tile)
-    constexpr int KS1MAX = 16 * JT;
+    constexpr int KS1MAX = L1 == 0 ? 8 : (L1 == 1 ? 16 : 32);
 
     f32x16 gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];
     float gb3[AOUT];
@@ -343,7 +347,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     }
     STAMP_START
 
-    __syncthreads();  // every wave is done with the transposition buffers
+    __syncthreads();  // every wave is done with the tile loop
     // per-lane partials -> per-unit sums through this pair's own LDS space
     const float db2_u = colsum(stgA, gb2, lane);  // d/d b2[lane]
     float dw3_u[L3_VALU ? AOUT : 1];              // d/d W3[k][lane] on the VALU path
@@ -360,49 +364,48 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) loss_acc += __shfl_xor(loss_acc, off);
-    __syncthreads();
+    __syncthreads();  // LDS (weights and transposition space) is free from here on
     const int o_b2 = ctx.P.b2 - ctx.base, o_w3 = ctx.P.w3 - ctx.base, o_b3 = ctx.P.b3 - ctx.base,
               o_loss = ctx.P.n;
-    for (int w = 0; w < FB_PAIRS; ++w) {
-        if (ctx.pair == w) {
-            const bool first = w == 0;
-            RED_PUT(o_b2 + lane, db2_u);
-            if constexpr (L3_VALU) {
+    RED_PUT(o_b2 + lane, db2_u);
+    if constexpr (L3_VALU) {
 #pragma unroll
-                for (int k = 0; k < AOUT; ++k)
-                    if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
-            } else {
+        for (int k = 0; k < AOUT; ++k)
+            if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
+    } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int act_row = rho(r, h);
-                        if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int act_row = rho(r, h);
+                if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
             }
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
-                const float lv = HEAD == HEAD_VALUE ? (float)(0.5 * loss_acc * (double)a.inv_n)
-                                                    : (float)(loss_acc * (double)a.inv_n);
-                RED_PUT(o_loss, lv);
-            }
-        }
-        __syncthreads();
     }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < AOUT; ++k) if (k < A) RED_PUT(o_b3 + k, gb3[k]);
+        const float lv = HEAD == HEAD_VALUE ? (float)(0.5 * loss_acc * (double)a.inv_n)
+                                            : (float)(loss_acc * (double)a.inv_n);
+        RED_PUT(o_loss, lv);
+    }
+    __syncthreads();  // the four arrays are complete
     STAMP(6)
     STAMP_FLUSH(a, ctx.pair)
 }
 
 // ------------------------------------------------------------------------------ backward wave
-template <int JT>
+template <int L1>
 __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx) {
     const NetLds& L = ctx.L;
-    const int S = ctx.S, h = ctx.h, c = ctx.c;
+    const int S = ctx.S, lane = ctx.lane, h = ctx.h, c = ctx.c;
     float* const stgA = ctx.stgA;
     float* const stgB = ctx.stgB;
     float* const stgC = ctx.stgC;
+    constexpr int JT = L1 == 2 ? 2 : 1;
+    constexpr bool NARROW = L1 == 0;  // S+1 <= 16: layer-1 wgrad on 16x16x4 tiles (half the MFMA time)
+    const int c16 = lane & 15, q4 = lane >> 4;
     f32x16 gW2[2][2], gW1[2][JT];
+    f32x4 gW1n[4];  // NARROW: tile it covers outputs 16*it .. 16*it+15, inputs 0..15
     STAMP_DECL
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -411,15 +414,38 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
 #pragma unroll
         for (int j = 0; j < JT; ++j) gW1[i][j] = 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gW1n[i] = 0.f;
+
     for (int it = 0; it < ctx.n_iter; ++it) {
         const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
         const int64_t m0 = tile * TILE_M;
         STAMP_START
-        // xp[s][jt] = X_aug[sample 2s+h][input 32*jt + c] for the layer-1 wgrad, fetched before
-        // the barriers so that it is long there when needed (lines the partner loaded a tile ago)
-        float xp[16][JT];
-        {
-            const bool full = m0 + TILE_M <= a.n;
+        // B operands of the layer-1 wgrad, X_aug[sample][input] (1 at input S, 0 beyond), fetched
+        // before the barriers so that they are long there when needed (lines the partner loaded a
+        // tile ago).  Wide: xp[s][jt] = X_aug[2s+h][32*jt+c].  Narrow: xq[s] = X_aug[4s+q4][c16].
+        float xp[NARROW ? 1 : 16][JT];
+        float xq[NARROW ? 8 : 1];
+        const bool full = m0 + TILE_M <= a.n;
+        if constexpr (NARROW) {
+            const float fill = c16 == S ? 1.0f : 0.0f;
+            const int inc = min(c16, S - 1);
+            if (full) {
+                const float* p0 = a.states + (m0 + q4) * S + inc;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float v = p0[(int64_t)(4 * s) * S];
+                    xq[s] = c16 < S ? v : fill;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int64_t gm = min(m0 + 4 * s + q4, a.n - 1);
+                    const float v = a.states[gm * S + inc];
+                    xq[s] = c16 < S ? v : fill;
+                }
+            }
+        } else {
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 const int in = 32 * jt + c;
@@ -482,48 +508,70 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         }
         STAMP(5)
         // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
+        if constexpr (NARROW) {
+            // v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int mm = 2 * s + h;
-            const float a0 = stgC[mm * STG_LD + c];
-            const float a1 = stgC[mm * STG_LD + 32 + c];
+            for (int s = 0; s < 8; ++s) {
+                const int mm = 4 * s + q4;
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
-                gW1[1][jt] = mfma32(a1, xp[s][jt], gW1[1][jt]);
+                for (int t4 = 0; t4 < 4; ++t4)
+                    gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(stgC[mm * STG_LD + 16 * t4 + c16],
+                                                                     xq[s], gW1n[t4], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int mm = 2 * s + h;
+                const float a0 = stgC[mm * STG_LD + c];
+                const float a1 = stgC[mm * STG_LD + 32 + c];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
+                    gW1[1][jt] = mfma32(a1, xp[s][jt], gW1[1][jt]);
+                }
             }
         }
+        STAMP(6)
     }
+    STAMP_START
 
-    __syncthreads();  // every wave is done with the transposition buffers
-    __syncthreads();  // (forward waves: per-unit sums done)
+    __syncthreads();  // every wave is done with the tile loop
+    __syncthreads();  // LDS (weights and transposition space) is free from here on
     const int o_w1 = ctx.P.w1 - ctx.base, o_b1 = ctx.P.b1 - ctx.base, o_w2 = ctx.P.w2 - ctx.base;
-    for (int w = 0; w < FB_PAIRS; ++w) {
-        if (ctx.pair == w) {
-            const bool first = w == 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int out = 32 * i + rho(r, h);
+        for (int r = 0; r < 16; ++r) {
+            const int out = 32 * i + rho(r, h);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) RED_PUT(o_w2 + out * HID + 32 * j + c, gW2[i][j][r]);
+            for (int j = 0; j < 2; ++j) RED_PUT(o_w2 + out * HID + 32 * j + c, gW2[i][j][r]);
+            if constexpr (!NARROW) {
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt) {
-                        const int in = 32 * jt + c;
-                        if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
-                        else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
-                    }
+                for (int jt = 0; jt < JT; ++jt) {
+                    const int in = 32 * jt + c;
+                    if (in < S) RED_PUT(o_w1 + out * S + in, gW1[i][jt][r])
+                    else if (in == S) RED_PUT(o_b1 + out, gW1[i][jt][r])
                 }
+            }
         }
-        __syncthreads();
+    if constexpr (NARROW) {
+        // C/D of the 16x16x4 tile: column (input) = lane & 15, row (output) = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int out = 16 * t4 + 4 * q4 + r;
+                if (c16 < S) RED_PUT(o_w1 + out * S + c16, gW1n[t4][r])
+                else if (c16 == S) RED_PUT(o_b1 + out, gW1n[t4][r])
+            }
     }
+    __syncthreads();  // the four arrays are complete
     STAMP(7)
     STAMP_FLUSH(a, FB_PAIRS + ctx.pair)
 }
 #undef RED_PUT
 
-template <int HEAD, int AOUT, int JT>
+template <int HEAD, int AOUT, int L1>
 __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     WaveCtx ctx;
     ctx.S = a.S;
@@ -542,7 +590,8 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     ctx.stgB = ctx.stgA + TILE_M * STG_LD;
     ctx.stgC = ctx.stgB + TILE_M * STG_LD;
     ctx.stgD = ctx.stgC + TILE_M * STG_LD;
-    ctx.red = stg;
+    const int red_stride = ctx.P.n + 1;
+    ctx.red = smem + ctx.pair * red_stride;  // valid once the tile loops are over
     ctx.n_tiles = (a.n + TILE_M - 1) / TILE_M;
     ctx.tstride = (int64_t)nwg * FB_PAIRS;
     ctx.tile0 = (int64_t)wg * FB_PAIRS + ctx.pair;
@@ -550,22 +599,23 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     fill_net_lds(ctx.L, a.params, ctx.P, a.S, ctx.A, AOUT, true);
     __syncthreads();
 
-    if (wave < FB_PAIRS) fwd_wave<HEAD, AOUT, JT>(a, ctx);
-    else bwd_wave<JT>(a, ctx);
+    if (wave < FB_PAIRS) fwd_wave<HEAD, AOUT, L1>(a, ctx);
+    else bwd_wave<L1>(a, ctx);
 
-    // (both wave kinds end on the last barrier of the workgroup reduction)
+    // (both wave kinds end on the barrier that completes the four per-pair arrays)
     float* dst = HEAD == HEAD_VALUE ? a.partial_critic + (size_t)wg * a.stride_critic
                                     : a.partial_actor + (size_t)wg * a.stride_actor;
-    for (int i = threadIdx.x; i < ctx.P.n + 1; i += FB_THREADS) dst[i] = ctx.red[i];
+    for (int i = threadIdx.x; i < red_stride; i += FB_THREADS)
+        dst[i] = ((smem[i] + smem[red_stride + i]) + smem[2 * red_stride + i]) + smem[3 * red_stride + i];
 }
 
-template <bool CONT, int AMAX, int JT>
+template <bool CONT, int AMAX, int L1>
 __global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs a) {
     extern __shared__ __align__(16) float smem[];
     if ((blockIdx.x & 1) == 0)
-        run_role<CONT ? HEAD_GAUSSIAN : HEAD_CATEGORICAL, AMAX, JT>(a, smem);
+        run_role<CONT ? HEAD_GAUSSIAN : HEAD_CATEGORICAL, AMAX, L1>(a, smem);
     else
-        run_role<HEAD_VALUE, 1, JT>(a, smem);
+        run_role<HEAD_VALUE, 1, L1>(a, smem);
 }
 
 // grad[p] = sum over the role's workgroups (fixed order, fp64 accumulate).  One block per 64
@@ -646,23 +696,25 @@ extern "C" int64_t ppo_param_count(int state_dim, int action_dim, int64_t* n_act
     return (int64_t)na + n_critic_params(state_dim);
 }
 
-static size_t fwdbwd_lds_bytes(int S, int amax) {
+static size_t fwdbwd_lds_bytes(int S, int A, int amax) {
     const int net = round4(net_lds_floats(S, amax, true));
-    return (size_t)(net + FB_PAIRS * STG_PAIR_FLOATS) * sizeof(float);
+    const int loop = net + FB_PAIRS * STG_PAIR_FLOATS;
+    const int red = FB_PAIRS * (n_actor_params(S, A) + 1);  // the actor's arrays are the larger ones
+    return (size_t)(loop > red ? loop : red) * sizeof(float);
 }
 
-template <bool CONT, int AMAX, int JT>
+template <bool CONT, int AMAX, int L1>
 static int launch_fwdbwd(const FwdBwdArgs& a, hipStream_t st) {
-    const size_t lds = fwdbwd_lds_bytes(a.S, AMAX);
+    const size_t lds = fwdbwd_lds_bytes(a.S, a.A, AMAX);
     if (lds > 160 * 1024) return PPO_E_UNSUPPORTED;
     static size_t configured = 0;
     if (lds > configured) {
-        const hipError_t e = hipFuncSetAttribute((const void*)fwdbwd_kernel<CONT, AMAX, JT>,
+        const hipError_t e = hipFuncSetAttribute((const void*)fwdbwd_kernel<CONT, AMAX, L1>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = lds;
     }
-    fwdbwd_kernel<CONT, AMAX, JT><<<FB_GRID, FB_THREADS, lds, st>>>(a);
+    fwdbwd_kernel<CONT, AMAX, L1><<<FB_GRID, FB_THREADS, lds, st>>>(a);
     return (int)hipGetLastError();
 }
 
@@ -710,20 +762,20 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
     a.partial_critic = (float*)((char*)workspace +
                                 align_up((size_t)(FB_GRID / 2) * a.stride_actor * sizeof(float), 256));
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = state_dim + 1 > 32;
+    const int l1 = state_dim + 1 <= 16 ? 0 : (state_dim + 1 <= 32 ? 1 : 2);
     const int amax = action_dim <= 2 ? 2 : (action_dim <= 4 ? 4 : 8);
+#define FB_DISPATCH_L1(C, AM)                                                            \
+    if (l1 == 0) return launch_fwdbwd<C, AM, 0>(a, st);                                  \
+    if (l1 == 1) return launch_fwdbwd<C, AM, 1>(a, st);                                  \
+    return launch_fwdbwd<C, AM, 2>(a, st);
 #define FB_DISPATCH(C)                                                                   \
-    if (!wide) {                                                                         \
-        if (amax == 2) return launch_fwdbwd<C, 2, 1>(a, st);                             \
-        if (amax == 4) return launch_fwdbwd<C, 4, 1>(a, st);                             \
-        return launch_fwdbwd<C, 8, 1>(a, st);                                            \
-    }                                                                                    \
-    if (amax == 2) return launch_fwdbwd<C, 2, 2>(a, st);                                 \
-    if (amax == 4) return launch_fwdbwd<C, 4, 2>(a, st);                                 \
-    return launch_fwdbwd<C, 8, 2>(a, st);
+    if (amax == 2) { FB_DISPATCH_L1(C, 2) }                                              \
+    if (amax == 4) { FB_DISPATCH_L1(C, 4) }                                              \
+    FB_DISPATCH_L1(C, 8)
     if (continuous) { FB_DISPATCH(true) }
     FB_DISPATCH(false)
 #undef FB_DISPATCH
+#undef FB_DISPATCH_L1
 }
 
 extern "C" int ppo_grad_reduce(int state_dim, int action_dim, const void* workspace,
