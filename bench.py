@@ -115,15 +115,10 @@ def main():
     it = [0]
 
     def iteration(timed_phases=None):
-        st = _lib.stream_ptr()
-        base = it[0] * T
-        for t in range(T):
-            xs = agent.next_state_slot(N)
-            rs, ds = agent.buffer.claim_env_slots(N)
-            _lib.check(L.ppo_synth_env_step(xs.data_ptr(), rs.data_ptr(), ds.data_ptr(), N, S,
-                                            cfg["reward_kind"], cfg["p_terminal"], base + t, T,
-                                            env_seed, st))
-            agent.act_inplace(N)
+        # T lockstep steps: synthetic env step (obs, reward, terminal) then batched act on the N
+        # states, written straight into the device buffer; then the K-epoch update.
+        agent.synthetic_rollout(N, T, cfg["reward_kind"], cfg["p_terminal"], step0=it[0] * T,
+                                env_seed=env_seed)
         if timed_phases is not None:
             torch.cuda.synchronize()
             timed_phases["rollout"] = time.perf_counter()

@@ -140,6 +140,24 @@ int ppo_synth_env_step(float* states_out, float* rewards_out, uint8_t* terminals
                        int64_t n_envs, int state_dim, int reward_kind, float p_terminal,
                        int64_t step, int64_t horizon, uint64_t seed, void* stream);
 
+/* A whole lockstep rollout of the synthetic envs: for t in [0, n_steps) one ppo_synth_env_step
+ * into rows [t*n_envs, (t+1)*n_envs) of the time-major buffers, then one ppo_act on those rows
+ * (rng_offset = act_offset0 + t).  Exactly the launches the per-step calls make, enqueued from C.
+ * Stands in for the loop of train.py:173-181 in the measurement harness. */
+int ppo_synth_rollout(const float* params, int state_dim, int action_dim, int continuous,
+                      float action_var, int64_t n_envs, int64_t n_steps, int reward_kind,
+                      float p_terminal, int64_t step0, int64_t horizon, uint64_t env_seed,
+                      uint64_t act_seed, uint64_t act_offset0, float* states, float* rewards,
+                      uint8_t* terminals, void* actions, float* logprobs, float* values,
+                      void* stream);
+
+/* Fused ppo_grad_reduce + ppo_adam_step for the single-process case (no all-reduce in between):
+ * same arithmetic, one launch.  grad_out (P + 2 floats) still receives the reduced gradient. */
+int ppo_reduce_adam_step(int state_dim, int action_dim, const void* workspace, size_t workspace_bytes,
+                         float* grad_out, float* params, float* exp_avg, float* exp_avg_sq,
+                         int64_t step, double lr_actor, double lr_critic, double beta1, double beta2,
+                         double eps, float* loss_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to before d
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libppo_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _SIGNATURES = {
     "ppo_hip_abi_version": (c_int, []),
@@ -36,6 +36,12 @@ _SIGNATURES = {
                               c_void_p]),
     "ppo_synth_env_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
                                    c_int64, c_int64, c_uint64, c_void_p]),
+    "ppo_synth_rollout": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int64, c_int64, c_int,
+                                  c_float, c_int64, c_int64, c_uint64, c_uint64, c_uint64, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppo_reduce_adam_step": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_int64, c_double, c_double, c_double, c_double,
+                                     c_double, c_void_p, c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

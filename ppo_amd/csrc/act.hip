@@ -184,6 +184,33 @@ __global__ __launch_bounds__(256) void synth_env_kernel(float* __restrict__ stat
 
 extern "C" int ppo_synth_env_step(float* states_out, float* rewards_out, uint8_t* terminals_out,
                                   int64_t n_envs, int state_dim, int reward_kind, float p_terminal,
+                                  int64_t step, int64_t horizon, uint64_t seed, void* stream);
+
+extern "C" int ppo_synth_rollout(const float* params, int state_dim, int action_dim, int continuous,
+                                 float action_var, int64_t n_envs, int64_t n_steps, int reward_kind,
+                                 float p_terminal, int64_t step0, int64_t horizon, uint64_t env_seed,
+                                 uint64_t act_seed, uint64_t act_offset0, float* states, float* rewards,
+                                 uint8_t* terminals, void* actions, float* logprobs, float* values,
+                                 void* stream) {
+    if (n_steps <= 0 || n_envs <= 0) return PPO_E_BADARG;
+    const size_t arow = continuous ? (size_t)action_dim * sizeof(float) : sizeof(int);
+    for (int64_t t = 0; t < n_steps; ++t) {
+        const size_t r0 = (size_t)t * n_envs;
+        int rc = ppo_synth_env_step(states + r0 * state_dim, rewards + r0, terminals + r0, n_envs,
+                                    state_dim, reward_kind, p_terminal, step0 + t, horizon, env_seed,
+                                    stream);
+        if (rc) return rc;
+        rc = launch_act<true>(params, state_dim, action_dim, continuous, action_var,
+                              states + r0 * state_dim, n_envs, act_seed, act_offset0 + t,
+                              (char*)actions + r0 * arow, logprobs + r0, values + r0, nullptr,
+                              (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int ppo_synth_env_step(float* states_out, float* rewards_out, uint8_t* terminals_out,
+                                  int64_t n_envs, int state_dim, int reward_kind, float p_terminal,
                                   int64_t step, int64_t horizon, uint64_t seed, void* stream) {
     if (n_envs <= 0 || state_dim < 1 || horizon < 1) return PPO_E_BADARG;
     const int grid = (int)((n_envs + 255) / 256);

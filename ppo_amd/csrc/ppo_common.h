@@ -20,7 +20,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define HID PPO_HIDDEN
 #define TILE_M 32   // samples per wave tile
-#define STG_LD 65   // row stride (floats) of the per-wave transposition buffers: odd => conflict-free
 
 #define HEAD_CATEGORICAL 0
 #define HEAD_GAUSSIAN 1
@@ -96,14 +95,21 @@ __device__ __forceinline__ f32x16 tanh16_prescaled(f32x16 v) {
 }
 
 // ------------------------------------------------------------------ LDS image of one MLP
-// w1t: [2*KS1][64]  row k (< S: input k; == S: bias b1; > S: zero), column = hidden unit; x TANH_PRESCALE
-// w2t: [64][64]     [in][out]  (forward A operand: lanes run over `out`); x TANH_PRESCALE, as is b2
-// w2n: [64][64]     [out][in]  (dgrad A operand: lanes run over `in`); absent for forward-only
+// w1t: [2*KS1][64]   row k (< S: input k; == S: bias b1; > S: zero), column = hidden unit; x TANH_PRESCALE
+// w2f: [64][W2_LD]   W2[out][in] x TANH_PRESCALE (as is b2).  Forward A operand: lane (c, h) reads
+//                    four consecutive `in` of row `out` = c (+32) with one 16-byte load, which feeds
+//                    four k-steps, because registers 4q..4q+3 of an accumulator tile are the four
+//                    consecutive units 8q + 4h .. +3.
+// w2b: [64][W2_LD]   W2^T, [in][out], unscaled (dgrad A operand, same access pattern); absent for
+//                    forward-only kernels
 // b2 : [64], w3: [AOUT][64] (rows >= A zero), b3: [AOUT]
+// W2_LD = 68: rows 16-byte aligned, and eight consecutive rows start 4 banks apart, so a 16-byte
+// access per lane is conflict-free.
+#define W2_LD 68
 struct NetLds {
     float* w1t;
-    float* w2t;
-    float* w2n;
+    float* w2f;
+    float* w2b;
     float* b2;
     float* w3;
     float* b3;
@@ -112,15 +118,15 @@ struct NetLds {
 __host__ __device__ inline int ks1_of(int S) { return (S + 2) / 2; }  // ceil((S+1)/2) k-steps
 
 __host__ __device__ inline int net_lds_floats(int S, int aout, bool bwd) {
-    return 2 * ks1_of(S) * HID + HID * HID * (bwd ? 2 : 1) + HID + aout * HID + ((aout + 3) & ~3);
+    return 2 * ks1_of(S) * HID + HID * W2_LD * (bwd ? 2 : 1) + HID + aout * HID + ((aout + 3) & ~3);
 }
 
 __device__ inline NetLds carve_net_lds(float* base, int S, int aout, bool bwd) {
     NetLds L;
     L.w1t = base;
-    L.w2t = L.w1t + 2 * ks1_of(S) * HID;
-    L.w2n = bwd ? L.w2t + HID * HID : nullptr;
-    L.b2 = L.w2t + HID * HID * (bwd ? 2 : 1);
+    L.w2f = L.w1t + 2 * ks1_of(S) * HID;
+    L.w2b = bwd ? L.w2f + HID * W2_LD : nullptr;
+    L.b2 = L.w2f + HID * W2_LD * (bwd ? 2 : 1);
     L.w3 = L.b2 + HID;
     L.b3 = L.w3 + aout * HID;
     return L;
@@ -140,12 +146,47 @@ __device__ inline void fill_net_lds(const NetLds& L, const float* __restrict__ p
     }
     for (int i = tid; i < HID * HID; i += nt) {
         const float v = params[P.w2 + i];  // W2[out = i>>6][in = i&63]
-        L.w2t[(i & 63) * HID + (i >> 6)] = v * TANH_PRESCALE;
-        if (bwd) L.w2n[i] = v;
+        L.w2f[(i >> 6) * W2_LD + (i & 63)] = v * TANH_PRESCALE;
+        if (bwd) L.w2b[(i & 63) * W2_LD + (i >> 6)] = v;
     }
     for (int i = tid; i < HID; i += nt) L.b2[i] = params[P.b2 + i] * TANH_PRESCALE;
     for (int i = tid; i < aout * HID; i += nt) L.w3[i] = (i >> 6) < A ? params[P.w3 + i] : 0.f;
     for (int i = tid; i < aout; i += nt) L.b3[i] = i < A ? params[P.b3 + i] : 0.f;
+}
+
+// Layer 2 of the forward pass: Z2 = W2 H1 + b2 (prescaled), tanh.  H1 stays in registers as the B
+// operand; the A operand comes from w2f, one 16-byte LDS load per four k-steps and row half.
+__device__ __forceinline__ void mlp_layer2(const NetLds& L, int c, int h, const f32x16 (&H1)[2],
+                                           f32x16 (&H2)[2]) {
+    f32x16 y0, y1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&L.b2[8 * q + 4 * h]);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(&L.b2[32 + 8 * q + 4 * h]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y0[4 * q + j] = b0[j];
+            y1[4 * q + j] = b1[j];
+        }
+    }
+    const float* row0 = L.w2f + c * W2_LD + 4 * h;
+    const float* row1 = row0 + 32 * W2_LD;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(row0 + 32 * st + 8 * q);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(row1 + 32 * st + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float b = H1[st][4 * q + j];  // unit 32*st + 8q + 4h + j
+                y0 = mfma32(a0[j], b, y0);
+                y1 = mfma32(a1[j], b, y1);
+            }
+        }
+    }
+    H2[0] = tanh16_prescaled(y0);
+    H2[1] = tanh16_prescaled(y1);
 }
 
 // ------------------------------------------------------------------ forward of one 32-sample tile
@@ -166,26 +207,7 @@ __device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __res
     }
     H1[0] = tanh16_prescaled(z0);
     H1[1] = tanh16_prescaled(z1);
-    f32x16 y0, y1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        y0[r] = L.b2[rho(r, h)];
-        y1[r] = L.b2[32 + rho(r, h)];
-    }
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = 32 * st + rho(r, h);
-            const float b = H1[st][r];
-            const float a0 = L.w2t[k * HID + c];
-            const float a1 = L.w2t[k * HID + 32 + c];
-            y0 = mfma32(a0, b, y0);
-            y1 = mfma32(a1, b, y1);
-        }
-    }
-    H2[0] = tanh16_prescaled(y0);
-    H2[1] = tanh16_prescaled(y1);
+    mlp_layer2(L, c, h, H1, H2);
 }
 
 // o[a] = b3[a] + sum_u W3[a][u] * H2[u]; each lane sums its 32 units, the two halves are added.

@@ -12,8 +12,8 @@
 // tiles of 32 samples:
 //   forward wave   layer 1, tanh, layer 2, tanh, output layer, distribution head, loss, gradient
 //                  w.r.t. the head inputs, dZ2 = (W3^T dout)(1 - H2^2); keeps the output layer's
-//                  and b2's gradient sums; hands dZ2 and H1 to its partner through LDS, transposed
-//                  ([sample][unit], odd row stride);
+//                  and b2's gradient sums; hands dZ2 and H1 to its partner through LDS as
+//                  [sample][unit] rows (16-byte stores: four consecutive units per register quad);
 //   backward wave  dgrad dH1^T = W2^T dZ2^T, dZ1, and the two big weight gradients
 //                  dW2 += dZ2^T H1, dW1 += dZ1^T [X 1], accumulated across all its tiles in MFMA
 //                  accumulator registers.
@@ -28,8 +28,16 @@
 #define FB_PAIRS 4
 #define FB_THREADS (FB_PAIRS * 2 * 64)
 #define FB_GRID 256                                    // one workgroup per CU; half per role
-#define STG_D 9                                        // row stride of the dout buffer
-#define STG_PAIR_FLOATS (3 * TILE_M * STG_LD + TILE_M * STG_D + 8)  // per-pair transposition space
+// Per-pair hand-off space.  Rows are samples, columns hidden units, row stride W2_LD (= 68: 16-byte
+// aligned rows whose starts are 4 banks apart, so 16-byte accesses of 8 consecutive rows and 4-byte
+// accesses of 32 consecutive columns are both conflict-free).
+//   dzs  [32][W2_LD]  dZ2[m][u2]  forward -> backward; the backward wave later reuses it for dZ1[m][u1]
+//   h1s  [32][W2_LD]  H1[m][u1]   forward -> backward (H2 while the MFMA output-layer wgrad runs)
+//   dtu  [9][DT_LD]   dout[a][m]  (MFMA output-layer wgrad only; row AOUT stays zero)
+#define DT_LD 36
+#define STG_MAT (TILE_M * W2_LD)
+#define STG_PAIR_FLOATS (2 * STG_MAT + 9 * DT_LD)
+#define CS_LD 65                                       // row stride of colsum()'s scratch: odd => conflict-free
 
 // Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
 // wave, written to a buffer registered with ppo_debug_set_stamps().  Never compiled into the product.
@@ -148,16 +156,16 @@ __device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const
     }
 }
 
-// Sum of per-lane partials over the 32 sample columns through `buf` (>= 32*STG_LD floats, private
+// Sum of per-lane partials over the 32 sample columns through `buf` (>= 32*CS_LD floats, private
 // to the calling wave): written as [register][lane], read back as 32 consecutive floats per hidden
 // unit; lane u returns unit u's total.  Fixed order, no cross-lane instructions.
 __device__ __forceinline__ float colsum(float* buf, const f32x16 (&v)[2], int lane) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[(16 * t + r) * STG_LD + lane] = v[t][r];
+        for (int r = 0; r < 16; ++r) buf[(16 * t + r) * CS_LD + lane] = v[t][r];
     const int q = lane & 31;
-    const float* src = buf + (16 * (lane >> 5) + (q & 3) + 4 * (q >> 3)) * STG_LD + 32 * ((q >> 2) & 1);
+    const float* src = buf + (16 * (lane >> 5) + (q & 3) + 4 * (q >> 3)) * CS_LD + 32 * ((q >> 2) & 1);
     float acc = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 32; ++cc) acc += src[cc];
@@ -171,10 +179,9 @@ struct WaveCtx {
     int base;          // first parameter of this MLP in the flat vector
     int S, A;
     int pair, lane, h, c;
-    float* stgA;       // dZ2   [32][STG_LD]   forward -> backward
-    float* stgB;       // H1    [32][STG_LD]   forward -> backward (H2 while the MFMA output wgrad runs)
-    float* stgC;       // dZ1   [32][STG_LD]   private to the backward wave
-    float* stgD;       // dout  [32][STG_D]
+    float* dzs;        // dZ2 [32][W2_LD], later dZ1
+    float* h1s;        // H1  [32][W2_LD]
+    float* dtu;        // dout [9][DT_LD]
     float* red;        // [P.n + 1] workgroup reduction buffer (aliases the transposition space)
     int64_t tile0, tstride, n_tiles;
     int n_iter;        // same for every wave of the grid: the barriers match
@@ -191,9 +198,9 @@ template <int HEAD, int AOUT, int L1>
 __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx) {
     const NetLds& L = ctx.L;
     const int S = ctx.S, A = ctx.A, lane = ctx.lane, h = ctx.h, c = ctx.c;
-    float* const stgA = ctx.stgA;
-    float* const stgB = ctx.stgB;
-    float* const stgD = ctx.stgD;
+    float* const dzs = ctx.dzs;
+    float* const h1s = ctx.h1s;
+    float* const dtu = ctx.dtu;
     constexpr bool L3_VALU = AOUT <= 2;  // output-layer wgrad on the VALU (A*32 FMAs per tile)
     constexpr int KS1MAX = L1 == 0 ? 8 : (L1 == 1 ? 16 : 32);
 
@@ -252,26 +259,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         }
         STAMP(0)
         // ---------------- layer 2
-        {
-            f32x16 y0, y1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                y0[r] = L.b2[rho(r, h)];
-                y1[r] = L.b2[32 + rho(r, h)];
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = 32 * st + rho(r, h);
-                    const float b = H1[st][r];
-                    y0 = mfma32(L.w2t[k * HID + c], b, y0);
-                    y1 = mfma32(L.w2t[k * HID + 32 + c], b, y1);
-                }
-            }
-            H2[0] = tanh16_prescaled(y0);
-            H2[1] = tanh16_prescaled(y1);
-        }
+        mlp_layer2(L, c, h, H1, H2);
         STAMP(1)
         float o[AOUT];
         out_layer<AOUT>(L, A, H2, h, o);
@@ -295,26 +283,38 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         __syncthreads();  // the partner has finished reading the previous tile's buffers
         STAMP(3)
 
+        float* const hrow = h1s + c * W2_LD + 4 * h;
         if constexpr (!L3_VALU) {
-            // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u], H2
-            // transposed through stgB before H1 takes its place
+            // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u]; k-step s of
+            // half-wave h is sample 16h + s.  H2 passes through h1s before H1 takes its place.
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) stgB[c * STG_LD + 32 * t + rho(r, h)] = H2[t][r];
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = H2[t][4 * q + j];
+                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q) = v;
+                }
             if (h == 0) {
 #pragma unroll
-                for (int k = 0; k < AOUT; ++k) stgD[c * STG_D + k] = dout[k];
+                for (int k = 0; k < AOUT; ++k) dtu[k * DT_LD + c] = dout[k];
             }
+            const float* arow = dtu + min(c, AOUT) * DT_LD + 16 * h;  // row AOUT is zero
+            const float* bcol = h1s + (16 * h) * W2_LD + c;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int mm = 2 * s + h;
-                const float av = c < AOUT ? stgD[mm * STG_D + c] : 0.f;
-                gW3[0] = mfma32(av, stgB[mm * STG_LD + c], gW3[0]);
-                gW3[1] = mfma32(av, stgB[mm * STG_LD + 32 + c], gW3[1]);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sm = 4 * g + j;
+                    gW3[0] = mfma32(av[j], bcol[sm * W2_LD], gW3[0]);
+                    gW3[1] = mfma32(av[j], bcol[sm * W2_LD + 32], gW3[1]);
+                }
             }
         }
         // ---------------- output layer backward: dZ2 = (W3^T dout) * (1 - H2^2), handed over
+        float* const zrow = dzs + c * W2_LD + 4 * h;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -330,15 +330,18 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                         g[3] = fmaf(w.w, dout[k], g[3]);
                     }
                 }
+                f32x4 dz4, h4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * q + j;
                     const float hv = H2[t][r];
                     const float dz = g[j] * (1.0f - hv * hv);
                     gb2[t][r] += dz;
-                    stgA[c * STG_LD + 32 * t + rho(r, h)] = dz;
-                    stgB[c * STG_LD + 32 * t + rho(r, h)] = H1[t][r];
+                    dz4[j] = dz;
+                    h4[j] = H1[t][r];
                 }
+                *reinterpret_cast<f32x4*>(zrow + 32 * t + 8 * q) = dz4;   // units 32t + 8q + 4h .. +3
+                *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q) = h4;
             }
         }
         STAMP(4)
@@ -349,11 +352,11 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
 
     __syncthreads();  // every wave is done with the tile loop
     // per-lane partials -> per-unit sums through this pair's own LDS space
-    const float db2_u = colsum(stgA, gb2, lane);  // d/d b2[lane]
+    const float db2_u = colsum(dzs, gb2, lane);  // d/d b2[lane]
     float dw3_u[L3_VALU ? AOUT : 1];              // d/d W3[k][lane] on the VALU path
     if constexpr (L3_VALU) {
 #pragma unroll
-        for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(stgA, gW3v[k], lane);
+        for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(dzs, gW3v[k], lane);
     }
 #pragma unroll
     for (int k = 0; k < AOUT; ++k) {
@@ -398,9 +401,8 @@ template <int L1>
 __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx) {
     const NetLds& L = ctx.L;
     const int S = ctx.S, lane = ctx.lane, h = ctx.h, c = ctx.c;
-    float* const stgA = ctx.stgA;
-    float* const stgB = ctx.stgB;
-    float* const stgC = ctx.stgC;
+    float* const dzs = ctx.dzs;
+    float* const h1s = ctx.h1s;
     constexpr int JT = L1 == 2 ? 2 : 1;
     constexpr bool NARROW = L1 == 0;  // S+1 <= 16: layer-1 wgrad on 16x16x4 tiles (half the MFMA time)
     const int c16 = lane & 15, q4 = lane >> 4;
@@ -417,13 +419,22 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
 #pragma unroll
     for (int i = 0; i < 4; ++i) gW1n[i] = 0.f;
 
+    // per-lane LDS addresses, loop-invariant
+    const float* const wrow0 = L.w2b + c * W2_LD + 4 * h;           // W2^T rows c and 32 + c
+    const float* const wrow1 = wrow0 + 32 * W2_LD;
+    float* const zrow = dzs + c * W2_LD + 4 * h;                     // this lane's sample row
+    const float* const hrow = h1s + c * W2_LD + 4 * h;
+    const float* const zcol = dzs + (16 * h) * W2_LD + c;            // k-step s <-> sample 16h + s
+    const float* const hcol = h1s + (16 * h) * W2_LD + c;
+    const float* const zcoln = dzs + q4 * W2_LD + c16;               // narrow: k-step s <-> sample 4s + q4
+
     for (int it = 0; it < ctx.n_iter; ++it) {
         const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
         const int64_t m0 = tile * TILE_M;
         STAMP_START
         // B operands of the layer-1 wgrad, X_aug[sample][input] (1 at input S, 0 beyond), fetched
         // before the barriers so that they are long there when needed (lines the partner loaded a
-        // tile ago).  Wide: xp[s][jt] = X_aug[2s+h][32*jt+c].  Narrow: xq[s] = X_aug[4s+q4][c16].
+        // tile ago).  Wide: xp[s][jt] = X_aug[16h+s][32*jt+c].  Narrow: xq[s] = X_aug[4s+q4][c16].
         float xp[NARROW ? 1 : 16][JT];
         float xq[NARROW ? 8 : 1];
         const bool full = m0 + TILE_M <= a.n;
@@ -452,16 +463,16 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                 const float fill = in == S ? 1.0f : 0.0f;
                 const int inc = min(in, S - 1);
                 if (full) {
-                    const float* p0 = a.states + (m0 + h) * S + inc;
+                    const float* p0 = a.states + (m0 + 16 * h) * S + inc;
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
-                        const float v = p0[(int64_t)(2 * s) * S];
+                        const float v = p0[(int64_t)s * S];
                         xp[s][jt] = in < S ? v : fill;
                     }
                 } else {
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
-                        const int64_t gm = min(m0 + 2 * s + h, a.n - 1);
+                        const int64_t gm = min(m0 + 16 * h + s, a.n - 1);
                         const float v = a.states[gm * S + inc];
                         xp[s][jt] = in < S ? v : fill;
                     }
@@ -474,56 +485,75 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         __syncthreads();  // buffers of this tile are complete
         STAMP(2)
 
-        // ---------------- dgrad of layer 2: dH1^T[in, m] = sum_out W2[out, in] dZ2[m, out]
+        // ---------------- dgrad of layer 2: dH1[in, m] = sum_out W2[out, in] dZ2[m, out]; the four
+        // k-steps of group g are output units 8g + 4h .. +3: one 16-byte load per operand
         f32x16 d0 = {0}, d1 = {0};
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int k = 2 * s + h;  // output unit of layer 2
-            const float b = stgA[c * STG_LD + k];
-            d0 = mfma32(L.w2n[k * HID + c], b, d0);
-            d1 = mfma32(L.w2n[k * HID + 32 + c], b, d1);
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(zrow + 8 * g);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(wrow0 + 8 * g);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(wrow1 + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d0 = mfma32(a0[j], b4[j], d0);
+                d1 = mfma32(a1[j], b4[j], d1);
+            }
         }
         STAMP(3)
-        // ---------------- through tanh: dZ1 = dH1 * (1 - H1^2); transposed into stgC
+        // ---------------- through tanh: dZ1 = dH1 * (1 - H1^2), kept in registers until the layer-2
+        // wgrad has read dZ2
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float h0 = stgB[c * STG_LD + rho(r, h)];
-            const float h1 = stgB[c * STG_LD + 32 + rho(r, h)];
-            stgC[c * STG_LD + rho(r, h)] = d0[r] * (1.0f - h0 * h0);
-            stgC[c * STG_LD + 32 + rho(r, h)] = d1[r] * (1.0f - h1 * h1);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(hrow + 8 * q);
+            const f32x4 h1 = *reinterpret_cast<const f32x4*>(hrow + 32 + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d0[4 * q + j] *= 1.0f - h0[j] * h0[j];
+                d1[4 * q + j] *= 1.0f - h1[j] * h1[j];
+            }
         }
         STAMP(4)
         // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int mm = 2 * s + h;
-            const float a0 = stgA[mm * STG_LD + c];
-            const float a1 = stgA[mm * STG_LD + 32 + c];
-            const float b0 = stgB[mm * STG_LD + c];
-            const float b1 = stgB[mm * STG_LD + 32 + c];
+            const float a0 = zcol[s * W2_LD];
+            const float a1 = zcol[s * W2_LD + 32];
+            const float b0 = hcol[s * W2_LD];
+            const float b1 = hcol[s * W2_LD + 32];
             gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
             gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
             gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
             gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
         }
         STAMP(5)
+        // ---------------- dZ1 takes dZ2's place (this wave's own reads of dZ2 are complete: LDS
+        // operations of one wave execute in order)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v0[j] = d0[4 * q + j];
+                v1[j] = d1[4 * q + j];
+            }
+            *reinterpret_cast<f32x4*>(zrow + 8 * q) = v0;
+            *reinterpret_cast<f32x4*>(zrow + 32 + 8 * q) = v1;
+        }
         // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
         if constexpr (NARROW) {
             // v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const int mm = 4 * s + q4;
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4)
-                    gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(stgC[mm * STG_LD + 16 * t4 + c16],
+                    gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(zcoln[4 * s * W2_LD + 16 * t4],
                                                                      xq[s], gW1n[t4], 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int mm = 2 * s + h;
-                const float a0 = stgC[mm * STG_LD + c];
-                const float a1 = stgC[mm * STG_LD + 32 + c];
+                const float a0 = zcol[s * W2_LD];
+                const float a1 = zcol[s * W2_LD + 32];
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
                     gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
@@ -586,10 +616,9 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     ctx.pair = wave & (FB_PAIRS - 1);
     ctx.L = carve_net_lds(smem, a.S, AOUT, true);
     float* stg = smem + round4(net_lds_floats(a.S, AOUT, true));
-    ctx.stgA = stg + ctx.pair * STG_PAIR_FLOATS;
-    ctx.stgB = ctx.stgA + TILE_M * STG_LD;
-    ctx.stgC = ctx.stgB + TILE_M * STG_LD;
-    ctx.stgD = ctx.stgC + TILE_M * STG_LD;
+    ctx.dzs = stg + ctx.pair * STG_PAIR_FLOATS;
+    ctx.h1s = ctx.dzs + STG_MAT;
+    ctx.dtu = ctx.h1s + STG_MAT;
     const int red_stride = ctx.P.n + 1;
     ctx.red = smem + ctx.pair * red_stride;  // valid once the tile loops are over
     ctx.n_tiles = (a.n + TILE_M - 1) / TILE_M;
@@ -597,6 +626,8 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     ctx.tile0 = (int64_t)wg * FB_PAIRS + ctx.pair;
     ctx.n_iter = (int)((ctx.n_tiles + ctx.tstride - 1) / ctx.tstride);
     fill_net_lds(ctx.L, a.params, ctx.P, a.S, ctx.A, AOUT, true);
+    for (int i = threadIdx.x; i < FB_PAIRS * 9 * DT_LD; i += FB_THREADS)
+        stg[(i / (9 * DT_LD)) * STG_PAIR_FLOATS + 2 * STG_MAT + i % (9 * DT_LD)] = 0.f;
     __syncthreads();
 
     if (wave < FB_PAIRS) fwd_wave<HEAD, AOUT, L1>(a, ctx);
@@ -669,6 +700,62 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ params,
     params[i] = params[i] + (ns * mi) / denom;  // param.addcdiv_(exp_avg, denom, value=-step_size)
     m[i] = mi;
     v[i] = vi;
+}
+
+// grad_reduce_kernel + adam_kernel in one launch (single process: nothing happens in between).
+__global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ partial_actor,
+                                                          const float* __restrict__ partial_critic,
+                                                          int stride_actor, int stride_critic,
+                                                          int n_actor, int n_critic, int rows,
+                                                          float* __restrict__ grad,
+                                                          float* __restrict__ params,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          float neg_step_actor, float neg_step_critic,
+                                                          float one_minus_b1, float b2,
+                                                          float one_minus_b2, float bc2_sqrt, float eps,
+                                                          float* __restrict__ loss_out) {
+#pragma clang fp contract(off)
+    __shared__ double part[4][64];
+    __shared__ float gsh[64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    const int P = n_actor + n_critic;
+    double s = 0.0;
+    if (i < P + 2) {
+        const float* src;
+        int stride;
+        if (i < n_actor) { src = partial_actor + i; stride = stride_actor; }
+        else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; }
+        else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; }
+        else { src = partial_critic + n_critic; stride = stride_critic; }
+        const int per = (rows + 3) / 4;
+        const int lo = grp * per, hi = min(rows, lo + per);
+#pragma unroll 8
+        for (int g = lo; g < hi; ++g) s += (double)src[(size_t)g * stride];
+    }
+    part[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < P + 2) {
+        const float g = (float)(((part[0][col] + part[1][col]) + part[2][col]) + part[3][col]);
+        grad[i] = g;
+        gsh[col] = g;
+        if (i < P) {
+            float mi = m[i], vi = v[i];
+            mi = mi + one_minus_b1 * (g - mi);
+            vi = vi * b2;
+            vi = vi + (one_minus_b2 * g) * g;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            const float ns = i < n_actor ? neg_step_actor : neg_step_critic;
+            params[i] = params[i] + (ns * mi) / denom;
+            m[i] = mi;
+            v[i] = vi;
+        }
+    }
+    __syncthreads();
+    // the two loss terms are entries P and P+1; the host only launches this kernel when both
+    // fall into one block
+    if (loss_out && threadIdx.x == 0 && (int)blockIdx.x == P / 64)
+        loss_out[0] = gsh[P & 63] + gsh[(P + 1) & 63];
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -815,7 +902,39 @@ extern "C" int ppo_adam_step(float* params, const float* grad, float* exp_avg, f
     return (int)hipGetLastError();
 }
 
-extern "C" int ppo_hip_abi_version(void) { return 1; }
+extern "C" int ppo_reduce_adam_step(int state_dim, int action_dim, const void* workspace,
+                                    size_t workspace_bytes, float* grad_out, float* params,
+                                    float* exp_avg, float* exp_avg_sq, int64_t step, double lr_actor,
+                                    double lr_critic, double beta1, double beta2, double eps,
+                                    float* loss_out, void* stream) {
+    if (!workspace || !grad_out || !params || !exp_avg || !exp_avg_sq || step < 1) return PPO_E_BADARG;
+    if (state_dim < 1 || state_dim > PPO_MAX_STATE_DIM || action_dim < 1 ||
+        action_dim > PPO_MAX_ACTION_DIM)
+        return PPO_E_UNSUPPORTED;
+    if (workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
+    const int na = n_actor_params(state_dim, action_dim), nc = n_critic_params(state_dim);
+    const int P = na + nc;
+    if ((P / 64) != ((P + 1) / 64)) {
+        // the two loss terms fall into different blocks: use the two-launch form
+        const int rc = ppo_grad_reduce(state_dim, action_dim, workspace, workspace_bytes, grad_out, stream);
+        if (rc) return rc;
+        return ppo_adam_step(params, grad_out, exp_avg, exp_avg_sq, P, na, step, lr_actor, lr_critic,
+                             beta1, beta2, eps, loss_out, stream);
+    }
+    const int sa = stride_of(na), sc = stride_of(nc);
+    const float* pa = (const float*)workspace;
+    const float* pc = (const float*)((const char*)workspace +
+                                     align_up((size_t)(FB_GRID / 2) * sa * sizeof(float), 256));
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    reduce_adam_kernel<<<(P + 2 + 63) / 64, 256, 0, (hipStream_t)stream>>>(
+        pa, pc, sa, sc, na, nc, FB_GRID / 2, grad_out, params, exp_avg, exp_avg_sq,
+        (float)(-(lr_actor / bc1)), (float)(-(lr_critic / bc1)), (float)(1.0 - beta1), (float)beta2,
+        (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, loss_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int ppo_hip_abi_version(void) { return 2; }
 
 extern "C" const char* ppo_hip_strerror(int code) {
     switch (code) {

@@ -386,6 +386,17 @@ class FusedAdam:
             self.step_count, g0['lr'], g1['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
             _lib.ptr(loss_out), _lib.stream_ptr()))
 
+    def reduce_and_step(self, state_dim, action_dim, ws, loss_out=None):
+        """grad <- fixed-order sum of the per-workgroup partials in `ws`, then step(): one launch."""
+        _require_gpu()
+        self.step_count += 1
+        g0, g1 = self.param_groups
+        _lib.check(_lib.lib().ppo_reduce_adam_step(
+            state_dim, action_dim, ws.data_ptr(), ws.numel(), self.grad.data_ptr(),
+            self.policy.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            self.step_count, g0['lr'], g1['lr'], g0['betas'][0], g0['betas'][1], g0['eps'],
+            _lib.ptr(loss_out), _lib.stream_ptr()))
+
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg.cpu(), 'exp_avg_sq': self.exp_avg_sq.cpu(),
                 'lr': [g['lr'] for g in self.param_groups]}
@@ -501,6 +512,29 @@ class PPO:
         self._pending_lo = lo
         return self.buffer.rows("states", lo, lo + n_envs)
 
+    def synthetic_rollout(self, n_envs, n_steps, reward_kind=0, p_terminal=1.0 / 200.0, step0=0,
+                          env_seed=1234):
+        """Measurement harness: n_steps lockstep steps of n_envs synthetic envs (ppo_synth_env_step)
+        each followed by the batched act, all launches enqueued by one C call.  Equivalent to calling
+        next_state_slot / claim_env_slots / ppo_synth_env_step / act_inplace n_steps times."""
+        _require_gpu()
+        b = self.buffer
+        n = n_envs * n_steps
+        lo = b.claim_step(n)
+        b._n_envs = n_envs
+        b._count["rewards"] += n
+        b._count["is_terminals"] += n
+        seed, off = self._next_rng()
+        self._rng_offset += n_steps - 1
+        pol = self.policy_old
+        _lib.check(_lib.lib().ppo_synth_rollout(
+            pol.flat.data_ptr(), self.state_dim, self.action_dim, int(self.has_continuous_action_space),
+            pol._var32(), n_envs, n_steps, reward_kind, p_terminal, step0, n_steps, env_seed, seed, off,
+            b.rows("states", lo, lo + n).data_ptr(), b.rows("rewards", lo, lo + n).data_ptr(),
+            b.rows("is_terminals", lo, lo + n).data_ptr(), b.rows("actions", lo, lo + n).data_ptr(),
+            b.rows("logprobs", lo, lo + n).data_ptr(), b.rows("state_values", lo, lo + n).data_ptr(),
+            _lib.stream_ptr()))
+
     def _act_rows(self, lo, n):
         b = self.buffer
         seed, off = self._next_rng()
@@ -565,6 +599,7 @@ class PPO:
             dbg = {k: torch.empty(T, dtype=torch.float32, device=device)
                    for k in ("logprobs", "state_values", "entropy", "surrogate")}
         var32 = pol._var32()
+        distributed = _dist.is_distributed()
         for e in range(self.K_epochs):
             d = dbg if (dbg is not None and e == 0) else None
             if self.kernel_events is not None:
@@ -582,6 +617,9 @@ class PPO:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
                 self.kernel_events.append((ev0, ev1))
+            if not distributed and not debug:
+                opt.reduce_and_step(self.state_dim, self.action_dim, ws, loss_out=losses[e:e + 1])
+                continue
             _lib.check(L.ppo_grad_reduce(self.state_dim, self.action_dim, ws.data_ptr(), ws.numel(),
                                          opt.grad.data_ptr(), st))
             _dist.all_reduce_sum(opt.grad)

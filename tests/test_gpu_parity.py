@@ -316,6 +316,52 @@ def test_update_deterministic(eng):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name", ["c1_cartpole", "c3_bipedal"])
+def test_fused_reduce_adam_equals_two_launch(eng, name):
+    """ppo_reduce_adam_step (one launch) == ppo_grad_reduce + ppo_adam_step, bit for bit; the
+    debug=True update takes the two-launch path."""
+    ppo, _ = eng
+    d = load_case(name)
+    outs = []
+    for debug in (False, True):
+        agent = agent_from_case(ppo, d, 4)
+        agent.update(debug=debug)
+        outs.append((agent.policy.flat.clone(), agent.last_loss.clone(),
+                     agent.optimizer.exp_avg.clone(), agent.optimizer.exp_avg_sq.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cont", [False, True])
+def test_synthetic_rollout_equals_per_step_calls(eng, cont):
+    """ppo_synth_rollout enqueues exactly the launches of the per-step API."""
+    ppo, _lib = eng
+    S, A, N, T = (6, 3, 200, 5) if cont else (4, 2, 333, 7)
+    cols = ("states", "actions", "logprobs", "state_values", "rewards", "is_terminals")
+    got = []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, cont, 0.5 if cont else None)
+        agent.buffer.reserve(N * T)
+        if fused:
+            agent.synthetic_rollout(N, T, reward_kind=int(cont), p_terminal=0.1, step0=3, env_seed=99)
+        else:
+            b = agent.buffer
+            for t in range(T):
+                slot = agent.next_state_slot(N)
+                r, term = b.claim_env_slots(N)
+                _lib.check(_lib.lib().ppo_synth_env_step(
+                    slot.data_ptr(), r.data_ptr(), term.data_ptr(), N, S, int(cont), 0.1, 3 + t, T, 99,
+                    _lib.stream_ptr()))
+                agent.act_inplace(N)
+        b = agent.buffer
+        got.append([b.rows(c, 0, N * T).clone() for c in cols])
+        agent.update()
+        got[-1].append(agent.policy.flat.clone())
+    for c, a, bb in zip(cols + ("params",), *got):
+        assert torch.equal(a, bb), c
+
+
 def test_batched_update_equals_flat_with_row_end_terminals(eng):
     """N lockstep envs x T steps through the tensor-valued buffer facade == the oracle's flat
     update of the env-major concatenation with every row end flagged terminal."""
