@@ -27,7 +27,7 @@
 
 #define FB_PAIRS 4
 #define FB_THREADS (FB_PAIRS * 2 * 64)
-#define FB_GRID 256                                    // one workgroup per CU; half per role
+#define FB_GRID 256                                    // one workgroup per CU, split between the roles
 // Per-pair hand-off space.  Rows are samples, columns hidden units, row stride W2_LD (= 68: 16-byte
 // aligned rows whose starts are 4 banks apart, so 16-byte accesses of 8 consecutive rows and 4-byte
 // accesses of 32 consecutive columns are both conflict-free).
@@ -71,8 +71,9 @@ struct FwdBwdArgs {
     float* out_val;
     float* out_ent;
     float* out_surr;
-    float* partial_actor;   // [FB_GRID/2][stride_actor]
-    float* partial_critic;  // [FB_GRID/2][stride_critic]
+    float* partial_actor;   // [n_actor_wg][stride_actor]
+    float* partial_critic;  // [FB_GRID - n_actor_wg][stride_critic]
+    int n_actor_wg;         // workgroups 0 .. n_actor_wg-1 train the actor, the rest the critic
     int stride_actor, stride_critic;
 };
 
@@ -608,7 +609,9 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     ctx.A = HEAD == HEAD_VALUE ? 1 : a.A;
     ctx.base = HEAD == HEAD_VALUE ? n_actor_params(a.S, a.A) : 0;
     ctx.P = net_layout(ctx.base, a.S, ctx.A);
-    const int wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
+    const bool critic = HEAD == HEAD_VALUE;
+    const int wg = critic ? blockIdx.x - a.n_actor_wg : blockIdx.x;
+    const int nwg = critic ? gridDim.x - a.n_actor_wg : a.n_actor_wg;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     ctx.lane = threadIdx.x & 63;
     ctx.h = ctx.lane >> 5;
@@ -643,7 +646,7 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
 template <bool CONT, int AMAX, int L1>
 __global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs a) {
     extern __shared__ __align__(16) float smem[];
-    if ((blockIdx.x & 1) == 0)
+    if ((int)blockIdx.x < a.n_actor_wg)
         run_role<CONT ? HEAD_GAUSSIAN : HEAD_CATEGORICAL, AMAX, L1>(a, smem);
     else
         run_role<HEAD_VALUE, 1, L1>(a, smem);
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs 
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial_actor,
                                                           const float* __restrict__ partial_critic,
                                                           int stride_actor, int stride_critic,
-                                                          int n_actor, int n_critic, int rows,
+                                                          int n_actor, int n_critic, int rows_actor, int rows_critic,
                                                           float* __restrict__ grad) {
     __shared__ double part[4][64];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -663,11 +666,11 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restric
     double s = 0.0;
     if (i < P + 2) {
         const float* src;
-        int stride;
-        if (i < n_actor) { src = partial_actor + i; stride = stride_actor; }
-        else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; }
-        else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; }
-        else { src = partial_critic + n_critic; stride = stride_critic; }
+        int stride, rows;
+        if (i < n_actor) { src = partial_actor + i; stride = stride_actor; rows = rows_actor; }
+        else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; rows = rows_critic; }
+        else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; rows = rows_actor; }
+        else { src = partial_critic + n_critic; stride = stride_critic; rows = rows_critic; }
         const int per = (rows + 3) / 4;
         const int lo = grp * per, hi = min(rows, lo + per);
 #pragma unroll 8
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ params,
 __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ partial_actor,
                                                           const float* __restrict__ partial_critic,
                                                           int stride_actor, int stride_critic,
-                                                          int n_actor, int n_critic, int rows,
+                                                          int n_actor, int n_critic, int rows_actor, int rows_critic,
                                                           float* __restrict__ grad,
                                                           float* __restrict__ params,
                                                           float* __restrict__ m, float* __restrict__ v,
@@ -723,11 +726,11 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
     double s = 0.0;
     if (i < P + 2) {
         const float* src;
-        int stride;
-        if (i < n_actor) { src = partial_actor + i; stride = stride_actor; }
-        else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; }
-        else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; }
-        else { src = partial_critic + n_critic; stride = stride_critic; }
+        int stride, rows;
+        if (i < n_actor) { src = partial_actor + i; stride = stride_actor; rows = rows_actor; }
+        else if (i < P) { src = partial_critic + (i - n_actor); stride = stride_critic; rows = rows_critic; }
+        else if (i == P) { src = partial_actor + n_actor; stride = stride_actor; rows = rows_actor; }
+        else { src = partial_critic + n_critic; stride = stride_critic; rows = rows_critic; }
         const int per = (rows + 3) / 4;
         const int lo = grp * per, hi = min(rows, lo + per);
 #pragma unroll 8
@@ -764,10 +767,20 @@ size_t ppo_scan_ws_bytes(int64_t n);  // scan.hip
 
 static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
 
+// Workgroups per role.  The actor's tiles cost more than the critic's (wider output layer, the
+// distribution head, for more than two outputs an extra MFMA weight gradient); measured ratios of
+// per-tile time are 1.09 (2 discrete actions) and 1.57 (6 continuous).  Depends on the action count
+// only, so every entry point derives the same split.
+static int actor_wgs(int A) {
+    const double r = 1.0 + (A > 2 ? 0.095 : 0.045) * A;
+    int n = (int)(FB_GRID * r / (1.0 + r) + 0.5);
+    return n < FB_GRID / 4 ? FB_GRID / 4 : (n > 3 * FB_GRID / 4 ? 3 * FB_GRID / 4 : n);
+}
+
 static size_t update_ws_bytes(int S, int A) {
-    const size_t rows = FB_GRID / 2;
-    return align_up(rows * stride_of(n_actor_params(S, A)) * sizeof(float), 256) +
-           align_up(rows * stride_of(n_critic_params(S)) * sizeof(float), 256);
+    const size_t na = actor_wgs(A), nc = FB_GRID - na;
+    return align_up(na * stride_of(n_actor_params(S, A)) * sizeof(float), 256) +
+           align_up(nc * stride_of(n_critic_params(S)) * sizeof(float), 256);
 }
 
 extern "C" size_t ppo_workspace_bytes(int state_dim, int action_dim, int64_t max_samples) {
@@ -846,8 +859,9 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
     a.stride_actor = stride_of(n_actor_params(state_dim, action_dim));
     a.stride_critic = stride_of(n_critic_params(state_dim));
     a.partial_actor = (float*)workspace;
+    a.n_actor_wg = actor_wgs(action_dim);
     a.partial_critic = (float*)((char*)workspace +
-                                align_up((size_t)(FB_GRID / 2) * a.stride_actor * sizeof(float), 256));
+                                align_up((size_t)a.n_actor_wg * a.stride_actor * sizeof(float), 256));
     hipStream_t st = (hipStream_t)stream;
     const int l1 = state_dim + 1 <= 16 ? 0 : (state_dim + 1 <= 32 ? 1 : 2);
     const int amax = action_dim <= 2 ? 2 : (action_dim <= 4 ? 4 : 8);
@@ -876,10 +890,10 @@ extern "C" int ppo_grad_reduce(int state_dim, int action_dim, const void* worksp
     const int sa = stride_of(na), sc = stride_of(nc);
     const float* pa = (const float*)workspace;
     const float* pc = (const float*)((const char*)workspace +
-                                     align_up((size_t)(FB_GRID / 2) * sa * sizeof(float), 256));
+                                     align_up((size_t)actor_wgs(action_dim) * sa * sizeof(float), 256));
     const int total = na + nc + 2;
     grad_reduce_kernel<<<(total + 63) / 64, 256, 0, (hipStream_t)stream>>>(pa, pc, sa, sc, na, nc,
-                                                                          FB_GRID / 2, grad_out);
+                                                                          actor_wgs(action_dim), FB_GRID - actor_wgs(action_dim), grad_out);
     return (int)hipGetLastError();
 }
 
@@ -924,11 +938,12 @@ extern "C" int ppo_reduce_adam_step(int state_dim, int action_dim, const void* w
     const int sa = stride_of(na), sc = stride_of(nc);
     const float* pa = (const float*)workspace;
     const float* pc = (const float*)((const char*)workspace +
-                                     align_up((size_t)(FB_GRID / 2) * sa * sizeof(float), 256));
+                                     align_up((size_t)actor_wgs(action_dim) * sa * sizeof(float), 256));
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
     reduce_adam_kernel<<<(P + 2 + 63) / 64, 256, 0, (hipStream_t)stream>>>(
-        pa, pc, sa, sc, na, nc, FB_GRID / 2, grad_out, params, exp_avg, exp_avg_sq,
+        pa, pc, sa, sc, na, nc, actor_wgs(action_dim), FB_GRID - actor_wgs(action_dim), grad_out, params,
+        exp_avg, exp_avg_sq,
         (float)(-(lr_actor / bc1)), (float)(-(lr_critic / bc1)), (float)(1.0 - beta1), (float)beta2,
         (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, loss_out);
     return (int)hipGetLastError();

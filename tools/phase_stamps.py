@@ -47,10 +47,14 @@ fwd_names = ["L1 + tanh", "L2 + tanh", "out layer + head + L3 wgrad", "WAIT barr
              "dZ2 + hand-off writes", "WAIT barrier (written)", "epilogue"]
 bwd_names = ["xp loads issue", "WAIT barrier (free)", "WAIT barrier (written)", "dgrad", "dZ1 + transpose",
              "wgrad2", "wgrad1", "epilogue"]
-for role, sel in (("actor", slice(0, None, 2)), ("critic", slice(1, None, 2))):
+_r = 1.0 + (0.095 if A > 2 else 0.045) * A          # actor_wgs() of update.hip
+n_actor_wg = min(192, max(64, int(256 * _r / (1.0 + _r) + 0.5)))
+for role, sel in (("actor", slice(0, n_actor_wg)), ("critic", slice(n_actor_wg, 256))):
     for kind, ws, names in (("forward wave", slice(0, 4), fwd_names), ("backward wave", slice(4, 8), bwd_names)):
         rows = st[sel][:, ws].reshape(-1, 16)
         tot = rows[:, :len(names)].sum(1).mean()
-        print(f"{role} {kind}: mean cycles/wave {tot:.0f} ({tot / 32:.0f} per tile)")
+        n_wg = n_actor_wg if role == "actor" else 256 - n_actor_wg
+        tiles = (N * T / 32) / (n_wg * 4)
+        print(f"{role} {kind}: mean cycles/wave {tot:.0f} ({tot / tiles:.0f} per tile, {tiles:.1f} tiles/wave)")
         for i, nme in enumerate(names):
-            print(f"   {nme:30s} {rows[:, i].mean():10.0f}  {100 * rows[:, i].mean() / tot:5.1f}%  {rows[:, i].mean() / 32:7.0f}/tile")
+            print(f"   {nme:30s} {rows[:, i].mean():10.0f}  {100 * rows[:, i].mean() / tot:5.1f}%  {rows[:, i].mean() / tiles:7.0f}/tile")
