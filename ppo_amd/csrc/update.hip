@@ -316,20 +316,40 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         }
         // ---------------- output layer backward: dZ2 = (W3^T dout) * (1 - H2^2), handed over
         float* const zrow = dzs + c * W2_LD + 4 * h;
+        f32x16 G[2];
+        if constexpr (!L3_VALU) {
+            // G[u, m] = sum_a W3[a, u] dout[m, a] on the MFMA: k-step s covers outputs 2s and 2s+1
+            // (rows >= A of the LDS copy of W3 are zero); the result lands in the accumulator
+            // layout of H2, which is what the elementwise product needs
+            G[0] = 0.f;
+            G[1] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < AOUT / 2; ++s2) {
+                const float b = h ? dout[2 * s2 + 1] : dout[2 * s2];
+                const float* wr = L.w3 + (2 * s2 + h) * HID + c;
+                G[0] = mfma32(wr[0], b, G[0]);
+                G[1] = mfma32(wr[32], b, G[1]);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float g[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (L3_VALU) {
 #pragma unroll
-                for (int k = 0; k < AOUT; ++k) {
-                    if (k < A) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[k * HID + 32 * t + 8 * q + 4 * h]);
-                        g[0] = fmaf(w.x, dout[k], g[0]);
-                        g[1] = fmaf(w.y, dout[k], g[1]);
-                        g[2] = fmaf(w.z, dout[k], g[2]);
-                        g[3] = fmaf(w.w, dout[k], g[3]);
+                    for (int k = 0; k < AOUT; ++k) {
+                        if (k < A) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[k * HID + 32 * t + 8 * q + 4 * h]);
+                            g[0] = fmaf(w.x, dout[k], g[0]);
+                            g[1] = fmaf(w.y, dout[k], g[1]);
+                            g[2] = fmaf(w.z, dout[k], g[2]);
+                            g[3] = fmaf(w.w, dout[k], g[3]);
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = G[t][4 * q + j];
                 }
                 f32x4 dz4, h4;
 #pragma unroll
