@@ -11,20 +11,29 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
                                                   float* __restrict__ logprobs,
                                                   float* __restrict__ values,
                                                   float* __restrict__ entropy) {
+    // Even workgroups run the actor on four 32-sample tiles, odd ones the critic on the same
+    // tiles: each stages only its own network into LDS and the two halves of a step run side by side.
     extern __shared__ __align__(16) float smem[];
     const NetLayout PA = net_layout(0, S, A);
-    const NetLayout PC = net_layout(PA.n, S, 1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int64_t m = ((int64_t)(blockIdx.x >> 1) * 4 + wave) * TILE_M + c;
+    const bool valid = m < n;
+    f32x16 H1[2], H2[2];
+    if (blockIdx.x & 1) {
+        const NetLayout PC = net_layout(PA.n, S, 1);
+        const NetLds LC = carve_net_lds(smem, S, 1, false);
+        fill_net_lds(LC, params, PC, S, 1, 1, false);
+        __syncthreads();
+        mlp_fwd_tile(LC, states, S, m, valid, c, h, H1, H2);
+        float v[1];
+        out_layer<1>(LC, 1, H2, h, v);
+        if (valid && h == 0 && values) values[m] = v[0];
+        return;
+    }
     const NetLds LA = carve_net_lds(smem, S, AMAX, false);
-    const NetLds LC = carve_net_lds(smem + net_lds_floats(S, AMAX, false), S, 1, false);
     fill_net_lds(LA, params, PA, S, A, AMAX, false);
-    fill_net_lds(LC, params, PC, S, 1, 1, false);
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * TILE_M + c;
-    const bool valid = m < n;
-
-    f32x16 H1[2], H2[2];
     mlp_fwd_tile(LA, states, S, m, valid, c, h, H1, H2);
     float o[AMAX];
     out_layer<AMAX>(LA, A, H2, h, o);
@@ -90,12 +99,8 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
         ent = cat.ent;
     }
 
-    mlp_fwd_tile(LC, states, S, m, valid, c, h, H1, H2);
-    float v[1];
-    out_layer<1>(LC, 1, H2, h, v);
     if (valid && h == 0) {
         if (logprobs) logprobs[m] = logp;
-        if (values) values[m] = v[0];
         if (entropy) entropy[m] = ent;
     }
 }
@@ -108,9 +113,9 @@ static int launch_act(const float* params, int S, int A, int continuous, float a
     if (!params || !states || !actions || n <= 0) return PPO_E_BADARG;
     if (S < 1 || S > PPO_MAX_STATE_DIM || A < 1 || A > PPO_MAX_ACTION_DIM) return PPO_E_UNSUPPORTED;
     const int amax = A <= 4 ? 4 : 8;
-    const size_t lds = (size_t)(net_lds_floats(S, amax, false) + net_lds_floats(S, 1, false)) * 4;
+    const size_t lds = (size_t)net_lds_floats(S, amax, false) * 4;  // the actor's image is the larger
     const int64_t tiles = (n + TILE_M - 1) / TILE_M;
-    const int grid = (int)((tiles + 3) / 4);
+    const int grid = 2 * (int)((tiles + 3) / 4);
 #define ACT_LAUNCH(C, AM)                                                                       \
     {                                                                                           \
         static size_t configured = 0;                                                           \
