@@ -47,13 +47,14 @@ def cpu_baseline(cfg, threads):
     rng = np.random.default_rng(0)
     shapes = O.param_shapes(S, A)
     P = {k: (rng.standard_normal(s) * 0.1).astype(np.float32) for k, s in shapes.items()}
-    Ts, n_act, n_ep = 32768, 1500, 2
+    Ts, n_act, n_ep = 524288, 150000, 16      # 10-15 s of CPU work on the GPU box's host cores
     x = rng.standard_normal((Ts, S)).astype(np.float32)
     acts = (rng.standard_normal((Ts, A)).astype(np.float32) if cont else rng.integers(0, A, Ts))
     with threadpool_limits(limits=threads):
         t0 = time.perf_counter()
         for i in range(n_act):           # the reference acts one state per call (PPO.py:175-198)
-            O.act_logprob_value(P, x[i:i + 1], acts[i:i + 1], cont, std)
+            j = i % Ts
+            O.act_logprob_value(P, x[j:j + 1], acts[j:j + 1], cont, std)
         t_act = (time.perf_counter() - t0) / n_act
         r = rng.standard_normal(Ts).astype(np.float32)
         term = rng.random(Ts) < 1 / 200
@@ -70,7 +71,19 @@ def cpu_baseline(cfg, threads):
             O.adam_step(P, g, st, 3e-4, 1e-3)
         t_ep = (time.perf_counter() - t0) / (n_ep * Ts)
     per_step = t_act + t_scan + K * t_ep
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    import torch
     return {"value": 1.0 / per_step, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "host": {"cpu_model": model, "os_cpu_count": os.cpu_count(),
+                     "torch_num_threads": torch.get_num_threads(), "blas_threads_used": threads},
             "sample": f"numpy restatement: {n_act} single-state act calls, scan+normalise of {Ts} "
                       f"steps, {n_ep} update epochs over {Ts} samples; extrapolated to K={K}",
             "us_per_step": {"act": t_act * 1e6, "scan": t_scan * 1e6, "epoch": t_ep * 1e6}}
