@@ -151,6 +151,21 @@ int ppo_synth_rollout(const float* params, int state_dim, int action_dim, int co
                       uint8_t* terminals, void* actions, float* logprobs, float* values,
                       void* stream);
 
+/* ---- device-side vectorised CartPole-v1 ---------------------------------------------------------
+ * The env on the other side of select_action: env.reset() (train.py:170) and env.step(action)
+ * (train.py:177) of gym's CartPole-v1 (train.py:19,136) for n_envs independent envs in lockstep.
+ * state [n,4] fp64, steps [n] int32, episodes [n] uint32 are the envs' own storage; fin_sum [n] f32
+ * and fin_cnt [n] int32 (both may be NULL) accumulate the returns / number of finished episodes per
+ * env for logging.  ppo_cartpole_step integrates one step, writes reward (1.0) and terminal flag
+ * (pole fell, cart left the track, or max_episode_steps reached), resets finished envs in the
+ * same call and writes the observation the next select_action has to see. */
+int ppo_cartpole_reset(double* state, int* steps, unsigned* episodes, float* fin_sum, int* fin_cnt,
+                       float* obs_out, int64_t n_envs, uint64_t seed, void* stream);
+int ppo_cartpole_step(double* state, int* steps, unsigned* episodes, float* fin_sum, int* fin_cnt,
+                      const int* actions, float* obs_out, float* rewards_out,
+                      uint8_t* terminals_out, int64_t n_envs, int max_episode_steps, uint64_t seed,
+                      void* stream);
+
 /* Fused ppo_grad_reduce + ppo_adam_step for the single-process case (no all-reduce in between):
  * same arithmetic, one launch.  grad_out (P + 2 floats) still receives the reduced gradient. */
 int ppo_reduce_adam_step(int state_dim, int action_dim, const void* workspace, size_t workspace_bytes,

@@ -1,0 +1,101 @@
+"""Device-side environments and the training drivers (need the GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cartpole_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def envs():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ppo_amd import envs as E
+    return E
+
+
+@pytest.mark.parametrize("n", [1, 77, 1024])
+def test_cartpole_kernel_matches_restatement(envs, n):
+    """Kernel == numpy restatement of CartPole-v1 over 300 lockstep steps with resets: flags and
+    episode statistics exactly, fp64 state to 1e-12 (sin/cos may differ in the last ulp)."""
+    env = envs.CartPoleVecEnv(n)
+    env.seed(12345)
+    ref = CO.VecCartPole(n, 12345)
+    obs = env.reset()
+    assert np.array_equal(obs.cpu().numpy(), ref.reset())
+    rng = np.random.default_rng(n)
+    for t in range(300):
+        a = rng.integers(0, 2, n)
+        o, r, d, _ = env.step(torch.from_numpy(a).to("cuda", torch.int32))
+        ro, rr, rd = ref.step(a)
+        assert np.array_equal(d.cpu().numpy().astype(bool), rd), t
+        assert np.array_equal(r.cpu().numpy(), rr)
+        np.testing.assert_allclose(env._state.cpu().numpy(), ref.state, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(o.cpu().numpy(), ro, rtol=0, atol=1e-7)
+    assert np.array_equal(env.finished_count.cpu().numpy(), ref.fin_cnt)
+    assert np.array_equal(env.finished_return_sum.cpu().numpy(), ref.fin_sum)
+    assert ref.fin_cnt.sum() > 0
+
+
+def test_cartpole_time_limit(envs):
+    """An episode that never falls ends at max_episode_steps with done = 1 (gym's TimeLimit)."""
+    env = envs.CartPoleVecEnv(4)
+    env.max_episode_steps = 7
+    env.seed(1)
+    env.reset()
+    a = torch.zeros(4, dtype=torch.int32, device="cuda")
+    flags = []
+    for t in range(14):
+        a = 1 - a                                   # alternate pushes: stays up for 7 steps
+        _, _, d, _ = env.step(a)
+        flags.append(d.cpu().numpy().copy())
+    flags = np.array(flags)
+    assert flags[6].all() and flags[13].all() and flags[:6].sum() == 0 and flags[7:13].sum() == 0
+
+
+def test_single_env_reference_protocol(envs):
+    """n_envs = 1 speaks the reference's protocol: ndarray state, float reward, bool done."""
+    env = envs.make("CartPole-v1")
+    s = env.reset()
+    assert isinstance(s, np.ndarray) and s.shape == (4,) and s.dtype == np.float32
+    s2, r, d, info = env.step(1)
+    assert isinstance(s2, np.ndarray) and isinstance(r, float) and isinstance(d, bool) and info == {}
+    assert env.observation_space.shape == (4,) and env.action_space.n == 2
+
+
+def test_train_synth_single_env_call_sequence(envs, tmp_path):
+    """The per-step driver (train.py's call sequence) runs, logs in the reference's CSV format and
+    writes a checkpoint the evaluation driver loads."""
+    import test_synth
+    import train_synth
+    args = train_synth.parse_args([
+        "--n-envs", "1", "--max-training-timesteps", "1200", "--max-ep-len", "100", "--k-epochs", "4",
+        "--log-dir", str(tmp_path / "logs"), "--checkpoint-dir", str(tmp_path / "ck"), "--random-seed", "3",
+        "--save-model-freq", "400", "--quiet"])
+    agent, history, ck, log = train_synth.train(args)
+    lines = open(log).read().strip().split("\n")
+    assert lines[0] == "episode,timestep,reward" and len(lines) >= 3
+    ep, ts, rew = lines[1].split(",")
+    assert int(ts) == 200 and int(ep) > 0 and float(rew) > 0
+    assert os.path.exists(ck)
+    avg = test_synth.test(["--checkpoint", ck, "--episodes", "3", "--max-ep-len", "50", "--quiet"])
+    assert 1.0 <= avg <= 50.0
+
+
+def test_train_synth_vectorised_learns_cartpole(envs, tmp_path):
+    """512 lockstep CartPole envs, 30 updates: the average episode return rises well above the
+    random policy's (~22 steps), i.e. rollout, scan, update and env kernels work together."""
+    import train_synth
+    args = train_synth.parse_args([
+        "--n-envs", "512", "--horizon", "64", "--max-training-timesteps", str(512 * 64 * 30),
+        "--k-epochs", "10", "--log-dir", str(tmp_path / "logs"), "--checkpoint-dir", str(tmp_path / "ck"),
+        "--random-seed", "1", "--quiet"])
+    agent, history, ck, log = train_synth.train(args)
+    first = history[0][1]
+    best = max(h[1] for h in history)
+    assert first < 40.0
+    assert best > 3.0 * first and best > 80.0, history
