@@ -131,6 +131,17 @@ int ppo_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
                   double lr_critic, double beta1, double beta2, double eps, float* loss_out,
                   void* stream);
 
+/* ---- single-env latency path -------------------------------------------------------------------
+ * PPO.select_action as the reference's loop calls it (PPO.py:175-198, train.py:176): ONE state on
+ * the host in, ONE action on the host out.  Copies host_state (state_dim floats; page-locked memory
+ * makes the copy asynchronous) into state_row, runs ppo_act on that row (n = 1), copies the action
+ * (int32, or action_dim floats) to host_action_out and waits for the stream.  state_row /
+ * action_row / logprob_row / value_row are the rollout buffer's device rows for this step. */
+int ppo_act_host(const float* params, int state_dim, int action_dim, int continuous, float action_var,
+                 const float* host_state, float* state_row, uint64_t seed, uint64_t rng_offset,
+                 void* action_row, float* logprob_row, float* value_row, void* host_action_out,
+                 void* stream);
+
 /* ---- synthetic vectorised environment (measurement harness) ---------------------------------
  * One lockstep step of n_envs synthetic envs: observations ~ N(0,1), reward 1.0 (kind 0) or
  * ~N(0,1) (kind 1), terminal ~ Bernoulli(p_terminal) or, when p_terminal < 0, exactly at steps

@@ -36,6 +36,8 @@ _SIGNATURES = {
                               c_void_p]),
     "ppo_synth_env_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
                                    c_int64, c_int64, c_uint64, c_void_p]),
+    "ppo_act_host": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_uint64, c_uint64,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppo_cartpole_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_uint64, c_void_p]),
     "ppo_cartpole_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

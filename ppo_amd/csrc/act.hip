@@ -147,6 +147,28 @@ extern "C" int ppo_act(const float* params, int state_dim, int action_dim, int c
                             rng_offset, actions, logprobs, values, nullptr, (hipStream_t)stream);
 }
 
+// Single-env latency path (select_action as train.py:176 calls it, one state per call): host state
+// in, host action out, one call.  The state is copied into its buffer row, the batched kernel acts
+// on that one row, the action is copied back and the stream is waited for; with page-locked host
+// buffers both copies are asynchronous and the only wait is the final one.
+extern "C" int ppo_act_host(const float* params, int state_dim, int action_dim, int continuous,
+                            float action_var, const float* host_state, float* state_row,
+                            uint64_t seed, uint64_t rng_offset, void* action_row, float* logprob_row,
+                            float* value_row, void* host_action_out, void* stream) {
+    if (!host_state || !state_row || !host_action_out) return PPO_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(state_row, host_state, (size_t)state_dim * sizeof(float),
+                                  hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    const int rc = launch_act<true>(params, state_dim, action_dim, continuous, action_var, state_row, 1,
+                                    seed, rng_offset, action_row, logprob_row, value_row, nullptr, st);
+    if (rc) return rc;
+    const size_t abytes = continuous ? (size_t)action_dim * sizeof(float) : sizeof(int);
+    e = hipMemcpyAsync(host_action_out, action_row, abytes, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(st);
+}
+
 extern "C" int ppo_evaluate(const float* params, int state_dim, int action_dim, int continuous,
                             float action_var, const float* states, const void* actions, int64_t n,
                             float* logprobs, float* values, float* entropy, void* stream) {

@@ -35,9 +35,20 @@ class _VecEnv:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.observation_space = _Space(shape=(state_dim,))
         self._seed = 0
-        self._obs = torch.zeros(self.n_envs, state_dim, dtype=torch.float32, device=self.device)
-        self._rew = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
-        self._done = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
+        # one allocation: [obs (N*S floats) | reward (N floats) | done (N bytes)], so that the
+        # single-env protocol fetches a whole step result with one device-to-host copy
+        n, S = self.n_envs, state_dim
+        self._packed = torch.zeros(n * S + n + (n + 3) // 4, dtype=torch.float32, device=self.device)
+        self._obs = self._packed[:n * S].view(n, S)
+        self._rew = self._packed[n * S:n * S + n]
+        self._done = self._packed[n * S + n:].view(torch.uint8)[:n]
+        if self.numpy_api:
+            self._pin_out = torch.zeros_like(self._packed, device="cpu").pin_memory()
+            self._pin_out_np = self._pin_out.numpy()
+            self._pin_done_np = self._pin_out[S + 1:].view(torch.uint8).numpy()
+            self._pin_act = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._pin_act_np = self._pin_act.numpy()
+            self._act_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def seed(self, s):
         self._seed = int(s)
@@ -46,9 +57,17 @@ class _VecEnv:
     def close(self):
         pass
 
+    def _fetch(self):
+        """Single-env protocol: the packed step result in page-locked host memory, one copy + wait."""
+        self._pin_out.copy_(self._packed, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        S = self.observation_space.shape[0]
+        return self._pin_out_np[:S].copy(), float(self._pin_out_np[S]), bool(self._pin_done_np[0])
+
     def _out(self):
         if self.numpy_api:
-            return self._obs[0].cpu().numpy(), float(self._rew[0].item()), bool(self._done[0].item()), {}
+            o, r, d = self._fetch()
+            return o, r, d, {}
         return self._obs, self._rew, self._done, {}
 
 
@@ -71,13 +90,15 @@ class CartPoleVecEnv(_VecEnv):
             self._state.data_ptr(), self._steps.data_ptr(), self._episodes.data_ptr(),
             self.finished_return_sum.data_ptr(), self.finished_count.data_ptr(), self._obs.data_ptr(),
             self.n_envs, self._seed, _lib.stream_ptr()))
-        return self._obs[0].cpu().numpy() if self.numpy_api else self._obs
+        return self._fetch()[0] if self.numpy_api else self._obs
 
     def step(self, action, obs_out=None, reward_out=None, done_out=None):
         """action: int (numpy_api) or an [N] integer device tensor.  The *_out tensors let a caller
         have the results written straight into its rollout buffer rows."""
         if self.numpy_api:
-            action = torch.tensor([int(action)], dtype=torch.int32, device=self.device)
+            self._pin_act_np[0] = int(action)
+            self._act_dev.copy_(self._pin_act, non_blocking=True)
+            action = self._act_dev
         elif action.dtype != torch.int32:
             action = action.to(torch.int32)
         obs = self._obs if obs_out is None else obs_out
@@ -121,7 +142,7 @@ class SyntheticVecEnv(_VecEnv):
 
     def reset(self):
         self._emit(False)
-        return self._obs[0].cpu().numpy() if self.numpy_api else self._obs
+        return self._fetch()[0] if self.numpy_api else self._obs
 
     def step(self, action):
         self._emit(True)

@@ -436,6 +436,7 @@ class PPO:
 
         # engine state
         self._rng_seed = None      # drawn from torch's generator on first use (honours torch.manual_seed)
+        self._pin = None           # page-locked staging of the single-env protocol, made on first use
         self._rng_offset = 0
         self._ws = None
         self._moments = torch.zeros(3, dtype=torch.float64, device=device)
@@ -482,6 +483,8 @@ class PPO:
         exactly as the reference.  N lockstep envs: ``state`` of shape [N, S] (ndarray or tensor)
         -> device tensor of N actions (int64 [N] or float32 [N, A]); nothing is copied to the host."""
         _require_gpu()
+        if not isinstance(state, torch.Tensor) and np.ndim(state) == 1:
+            return self._select_action_host(state)
         x = torch.as_tensor(state, dtype=torch.float32, device=device) \
             if not (isinstance(state, torch.Tensor) and state.dtype == torch.float32 and state.device == device) \
             else state
@@ -498,6 +501,30 @@ class PPO:
         if self.has_continuous_action_space:
             return act.detach().cpu().numpy().flatten()
         return int(act.item())
+
+    def _select_action_host(self, state):
+        """The reference's protocol, one host state per call (PPO.py:175-198): the state goes through
+        a page-locked staging buffer into its buffer row, the action comes back the same way, and the
+        whole step is one library call with one stream wait (ppo_act_host)."""
+        if self._pin is None:
+            self._pin = (torch.empty(self.state_dim, dtype=torch.float32).pin_memory(),
+                         torch.empty(max(self.action_dim, 1), dtype=torch.float32).pin_memory())
+            self._pin_np = (self._pin[0].numpy(), self._pin[1].numpy(),
+                            self._pin[1].numpy().view(np.int32))
+        self._pin_np[0][:] = state
+        b = self.buffer
+        lo = b.claim_step(1)
+        seed, off = self._next_rng()
+        pol = self.policy_old
+        cont = self.has_continuous_action_space
+        _lib.check(_lib.lib().ppo_act_host(
+            pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var32(),
+            self._pin[0].data_ptr(), b.rows("states", lo, lo + 1).data_ptr(), seed, off,
+            b.rows("actions", lo, lo + 1).data_ptr(), b.rows("logprobs", lo, lo + 1).data_ptr(),
+            b.rows("state_values", lo, lo + 1).data_ptr(), self._pin[1].data_ptr(), _lib.stream_ptr()))
+        if cont:
+            return self._pin_np[1][:self.action_dim].copy()
+        return int(self._pin_np[2][0])
 
     def act_inplace(self, n_envs):
         """Device-side env variant: the env has already written this step's states into

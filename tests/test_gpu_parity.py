@@ -362,6 +362,32 @@ def test_synthetic_rollout_equals_per_step_calls(eng, cont):
         assert torch.equal(a, bb), c
 
 
+@pytest.mark.parametrize("cont", [False, True])
+def test_single_state_host_path_equals_batched_rows(eng, cont):
+    """select_action(np.ndarray[S]) (page-locked staging, ppo_act_host) stores exactly what the
+    batched call stores for the same states, and returns the reference's Python types."""
+    ppo, _ = eng
+    S, A = (24, 4) if cont else (8, 4)
+    xs = np.random.default_rng(8).standard_normal((6, S)).astype(np.float32)
+    cols = ("states", "actions", "logprobs", "state_values")
+    got = []
+    for host in (True, False):
+        torch.manual_seed(21)
+        agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, cont, 0.4 if cont else None)
+        outs = []
+        for x in xs:
+            if host:
+                a = agent.select_action(x.astype(np.float64))       # gym hands over float64
+                assert isinstance(a, np.ndarray) and a.dtype == np.float32 if cont else isinstance(a, int)
+                outs.append(np.asarray(a))
+            else:
+                outs.append(agent.select_action(torch.from_numpy(x[None]).cuda()).cpu().numpy()[0])
+        got.append(([agent.buffer.rows(c, 0, 6).clone() for c in cols], np.array(outs)))
+    for c, a, b in zip(cols, got[0][0], got[1][0]):
+        assert torch.equal(a, b), c
+    assert np.array_equal(got[0][1], got[1][1])
+
+
 def test_batched_update_equals_flat_with_row_end_terminals(eng):
     """N lockstep envs x T steps through the tensor-valued buffer facade == the oracle's flat
     update of the env-major concatenation with every row end flagged terminal."""
