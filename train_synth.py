@@ -48,6 +48,9 @@ def parse_args(argv=None):
     ap.add_argument("--log-dir", default="PPO_logs")
     ap.add_argument("--checkpoint-dir", default="PPO_preTrained")
     ap.add_argument("--save-model-freq", type=int, default=int(2e4))
+    ap.add_argument("--inplace", action="store_true",
+                    help="N > 1: let the env write rewards/terminals straight into the rollout buffer rows "
+                         "(next_state_slot / act_inplace / claim_env_slots) instead of select_action + appends")
     ap.add_argument("--quiet", action="store_true")
     return ap.parse_args(argv)
 
@@ -137,11 +140,18 @@ def train(args):
         next_save = args.save_model_freq
         next_decay = args.action_std_decay_freq
         while time_step <= args.max_training_timesteps:
-            for _ in range(H):
-                actions = agent.select_action(obs)             # [N] device tensor
-                obs, rewards, dones, _ = env.step(actions)
-                agent.buffer.rewards.append(rewards)
-                agent.buffer.is_terminals.append(dones)
+            if args.inplace:
+                for _ in range(H):
+                    agent.next_state_slot(N).copy_(obs)
+                    actions = agent.act_inplace(N)
+                    r_row, d_row = agent.buffer.claim_env_slots(N)
+                    obs = env.step(actions, obs_out=obs, reward_out=r_row, done_out=d_row)[0]
+            else:
+                for _ in range(H):
+                    actions = agent.select_action(obs)             # [N] device tensor
+                    obs, rewards, dones, _ = env.step(actions)
+                    agent.buffer.rewards.append(rewards)
+                    agent.buffer.is_terminals.append(dones)
             time_step += N * H
             agent.update()
             if continuous and time_step >= next_decay:
