@@ -21,11 +21,11 @@ if ROOT not in sys.path:
 
 CONFIGS = {
     # BASELINE.json configs[3]: synthetic vectorised CartPole, 4096 envs/GPU x 128 steps
-    "c4": dict(name="synthetic CartPole-shaped (S=4, A=2 discrete), 4096 envs/GPU x 128 steps, K=80",
+    "c4": dict(name="synthetic CartPole-shaped (S=4, A=2 discrete), {n_envs} envs/GPU x {horizon} steps, K={K}",
                S=4, A=2, continuous=False, std=None, n_envs=4096, horizon=128, K=80,
                reward_kind=0, p_terminal=1.0 / 200.0),
     # BASELINE.json configs[4]: HalfCheetah-shaped continuous (obs 26, act 6), 65536 envs/GPU
-    "c5": dict(name="synthetic HalfCheetah-shaped (S=26, A=6 continuous), 65536 envs/GPU x 128 steps, K=80",
+    "c5": dict(name="synthetic HalfCheetah-shaped (S=26, A=6 continuous), {n_envs} envs/GPU x {horizon} steps, K={K}",
                S=26, A=6, continuous=True, std=0.6, n_envs=65536, horizon=128, K=80,
                reward_kind=1, p_terminal=-1.0),
 }
@@ -105,16 +105,29 @@ def main():
         cfg["K"] = args.k_epochs
     if args.n_envs:
         cfg["n_envs"] = args.n_envs
+    cfg["name"] = cfg["name"].format(**cfg)
 
     import torch
     import torch.distributed as td
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("PPO_BENCH_WATCHDOG"):     # rehearsal aid: dump the Python stacks of a stuck rank
+        import faulthandler
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        faulthandler.dump_traceback_later(int(os.environ["PPO_BENCH_WATCHDOG"]), exit=True,
+                                          file=open(os.path.join(ROOT, "gpurun_out", f"watchdog_rank{rank}.txt"), "w"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # one rank per GPU over RCCL; PPO_BENCH_BACKEND=gloo lets several ranks share one GPU to
+        # rehearse the distributed code path on a single-GPU box (not a measurement)
+        backend = os.environ.get("PPO_BENCH_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        os.environ["LOCAL_RANK"] = str(local)
         torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend)
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -155,7 +168,7 @@ def main():
     events = agent.kernel_events
     agent.kernel_events = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)

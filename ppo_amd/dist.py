@@ -32,17 +32,30 @@ def merge_moments_list(triples):
     return torch.stack([n, mean, m2])
 
 
+def _stage_through_host(t):
+    """gloo (the CPU backend the tests and single-GPU rehearsals use) gets host tensors: its
+    collectives on device tensors stage through the host anyway, and mixing them with host-side
+    barriers was seen to stall.  RCCL ("nccl") works on the device tensors directly."""
+    return t.is_cuda and td.get_backend() == "gloo"
+
+
 def merge_moments(moments):
     """moments: fp64 [3] on this rank -> merged over all ranks (same tensor if not distributed)."""
     if not is_distributed():
         return moments
     world = td.get_world_size()
-    parts = [torch.empty_like(moments) for _ in range(world)]
-    td.all_gather(parts, moments.contiguous())
-    return merge_moments_list(torch.stack(parts)).contiguous()
+    src = moments.cpu() if _stage_through_host(moments) else moments.contiguous()
+    parts = [torch.empty_like(src) for _ in range(world)]
+    td.all_gather(parts, src)
+    return merge_moments_list(torch.stack(parts)).contiguous().to(moments.device)
 
 
 def all_reduce_sum(t):
     if is_distributed():
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        if _stage_through_host(t):
+            h = t.cpu()
+            td.all_reduce(h, op=td.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
     return t

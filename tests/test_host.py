@@ -198,3 +198,40 @@ def test_two_shard_update_equals_single_buffer_gloo():
             want = d["grad_e1/" + k]
             assert rel_err(g[k], want, floor=float(np.abs(want).max())) < 1e-4, k
     assert np.array_equal(res[0][4], res[1][4])       # identical on both ranks
+
+
+def test_c_abi_argument_errors_without_touching_the_gpu():
+    """Argument validation happens before any HIP call: bad shapes, null pointers and short
+    workspaces come back as negative PPO_E_* codes with a text."""
+    import ctypes
+    from ppo_amd import _lib
+    L = _lib.lib()
+    E_BADARG, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3
+    na = ctypes.c_int64(0)
+    assert L.ppo_param_count(4, 2, ctypes.byref(na)) == 9155 and na.value == 4610
+    assert L.ppo_param_count(26, 6, None) == 12231
+    assert L.ppo_workspace_bytes(4, 2, 1600) > 0
+    # state_dim / action_dim beyond the supported range
+    assert L.ppo_act(1, 64, 2, 0, 0.0, 1, 8, 0, 0, 1, 1, 1, None) == E_UNSUPPORTED
+    assert L.ppo_act(1, 4, 9, 0, 0.0, 1, 8, 0, 0, 1, 1, 1, None) == E_UNSUPPORTED
+    # null pointers / empty batch
+    assert L.ppo_act(None, 4, 2, 0, 0.0, 1, 8, 0, 0, 1, 1, 1, None) == E_BADARG
+    assert L.ppo_act(1, 4, 2, 0, 0.0, 1, 0, 0, 0, 1, 1, 1, None) == E_BADARG
+    assert L.ppo_returns_scan_flat(None, 1, 1, 8, 0.99, 1, 1, 1, 1 << 20, None) == E_BADARG
+    # workspace missing or too small
+    assert L.ppo_epoch_fwdbwd(1, 4, 2, 0, 0.0, 1, 1, 1, 1, 1, 8, 8, 0.2, None, None, None, None,
+                              None, 0, None) == E_WORKSPACE
+    assert L.ppo_epoch_fwdbwd(1, 4, 2, 0, 0.0, 1, 1, 1, 1, 1, 8, 8, 0.2, None, None, None, None,
+                              1, 16, None) == E_WORKSPACE
+    assert L.ppo_epoch_fwdbwd(1, 64, 2, 0, 0.0, 1, 1, 1, 1, 1, 8, 8, 0.2, None, None, None, None,
+                              1, 1 << 30, None) == E_UNSUPPORTED
+    assert L.ppo_epoch_fwdbwd(1, 4, 2, 0, 0.0, 1, 1, 1, 1, 1, 8, 4, 0.2, None, None, None, None,
+                              1, 1 << 30, None) == E_BADARG          # n_global < n_local
+    assert L.ppo_grad_reduce(4, 2, 1, 16, 1, None) == E_WORKSPACE
+    assert L.ppo_adam_step(1, 1, 1, 1, 0, 0, 1, 3e-4, 1e-3, 0.9, 0.999, 1e-8, None, None) == E_BADARG
+    assert L.ppo_adam_step(1, 1, 1, 1, 10, 5, 0, 3e-4, 1e-3, 0.9, 0.999, 1e-8, None, None) == E_BADARG
+    assert L.ppo_cartpole_step(None, 1, 1, None, None, 1, 1, 1, 1, 4, 500, 0, None) == E_BADARG
+    for code in (E_BADARG, E_WORKSPACE, E_UNSUPPORTED):
+        assert len(L.ppo_hip_strerror(code)) > 5
+    with pytest.raises(RuntimeError):
+        _lib.check(E_UNSUPPORTED)
