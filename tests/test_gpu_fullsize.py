@@ -1,0 +1,112 @@
+"""The update kernels at the benchmark's full buffer size (524 288 samples, the C4 shape, and a
+HalfCheetah-shaped continuous buffer): parity with the CPU restatement on the full gradient, and
+the size-independent properties the path offers - linearity of the mean gradient over shards,
+bit-reproducibility, and the full iteration against its own per-step form."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_abs, rel_err
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        from ppo_amd import _lib, ppo
+    return ppo, _lib
+
+
+def _problem(S, A, cont, T, seed):
+    rng = np.random.default_rng(seed)
+    P = {k: (rng.standard_normal(s) * (0.3 if k.endswith("weight") else 0.1)).astype(np.float32)
+         for k, s in O.param_shapes(S, A).items()}
+    x = rng.standard_normal((T, S)).astype(np.float32)
+    std = 0.5 if cont else None
+    if cont:
+        acts = rng.standard_normal((T, A)).astype(np.float32)
+    else:
+        acts = rng.integers(0, A, T).astype(np.int64)
+    logp, V, _, _ = O.evaluate(P, x, acts, cont, std)
+    old = (logp + rng.standard_normal(T).astype(np.float32) * 0.15).astype(np.float32)   # ratios in and out of the clip range
+    adv = rng.standard_normal(T).astype(np.float32)
+    ret = rng.standard_normal(T).astype(np.float32)
+    return P, x, acts, old, adv, ret, std
+
+
+def _fwdbwd(_lib, P, S, A, cont, std, x, acts, old, adv, ret, lo, hi, n_global, outs=False):
+    L = _lib.lib()
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    flat = torch.from_numpy(O.flatten_params(P)).cuda()
+    n = hi - lo
+    xs, a = dev(x[lo:hi], torch.float32), dev(acts[lo:hi], torch.float32 if cont else torch.int32)
+    o, ad, r = (dev(v[lo:hi], torch.float32) for v in (old, adv, ret))
+    ws = torch.empty(L.ppo_workspace_bytes(S, A, n), dtype=torch.uint8, device="cuda")
+    grad = torch.empty(flat.numel() + 2, dtype=torch.float32, device="cuda")
+    extra = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(4)] if outs else [None] * 4
+    ptr = lambda t: None if t is None else t.data_ptr()
+    _lib.check(L.ppo_epoch_fwdbwd(flat.data_ptr(), S, A, int(cont), float(np.float32(std) ** 2) if cont else 0.0,
+                                  xs.data_ptr(), a.data_ptr(), o.data_ptr(), ad.data_ptr(), r.data_ptr(),
+                                  n, n_global, 0.2, ptr(extra[0]), ptr(extra[1]), ptr(extra[2]), ptr(extra[3]),
+                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    _lib.check(L.ppo_grad_reduce(S, A, ws.data_ptr(), ws.numel(), grad.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return grad.cpu().numpy(), [None if e is None else e.cpu().numpy() for e in extra]
+
+
+@pytest.mark.parametrize("S,A,cont,T", [(4, 2, False, 524288), (26, 6, True, 262144)])
+def test_full_size_gradient_matches_restatement_and_is_linear_over_shards(eng, S, A, cont, T):
+    _, _lib = eng
+    P, x, acts, old, adv, ret, std = _problem(S, A, cont, T, 7)
+    g_full, (lp, v, ent, surr) = _fwdbwd(_lib, P, S, A, cont, std, x, acts, old, adv, ret, 0, T, T, outs=True)
+    # (1) parity with the CPU restatement at this size: per-sample outputs and the whole gradient
+    out_w, grads_w = O.ppo_loss_and_grads(P, x, acts, old, adv, ret, 0.2, cont, std)
+    assert rel_err(lp, out_w["logprobs"]) < 1e-5 and rel_err(v, out_w["state_values"]) < 1e-5
+    assert rel_err(ent, out_w["entropy"]) < 1e-5
+    want = O.flatten_params(grads_w)
+    got = g_full[:-2]
+    assert max_abs(got, want) < 1e-4 * np.abs(want).max()
+    assert rel_err(g_full[-2] + g_full[-1], out_w["loss_mean"]) < 1e-5
+    # (2) linearity: the gradient of the mean over the buffer is the sum of the shards' gradients
+    #     when every shard scales by 1/n_global (what the data-parallel path relies on)
+    cut = (T * 3) // 8 + 5                                   # uneven, not a multiple of the tile
+    g_a, _ = _fwdbwd(_lib, P, S, A, cont, std, x, acts, old, adv, ret, 0, cut, T)
+    g_b, _ = _fwdbwd(_lib, P, S, A, cont, std, x, acts, old, adv, ret, cut, T, T)
+    assert max_abs(g_a + g_b, g_full) < 2e-6 * np.abs(g_full).max()
+    # (3) bit-reproducible
+    g_again, _ = _fwdbwd(_lib, P, S, A, cont, std, x, acts, old, adv, ret, 0, T, T)
+    assert np.array_equal(g_again, g_full)
+
+
+def test_full_size_iteration_equals_its_per_step_form(eng):
+    """One benchmark iteration (C-side rollout loop + fused reduce/Adam) leaves exactly the state
+    that the per-step public calls + the two-launch reduce/Adam leave."""
+    ppo, _lib = eng
+    N, T, K = 4096, 128, 3
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        agent = ppo.PPO(4, 2, 3e-4, 1e-3, 0.99, K, 0.2, False, None)
+        agent.buffer.reserve(N * T)
+        if fused:
+            agent.synthetic_rollout(N, T, 0, 1.0 / 200.0, step0=0, env_seed=1234)
+            agent.update()
+        else:
+            b = agent.buffer
+            for t in range(T):
+                slot = agent.next_state_slot(N)
+                r, term = b.claim_env_slots(N)
+                _lib.check(_lib.lib().ppo_synth_env_step(slot.data_ptr(), r.data_ptr(), term.data_ptr(), N, 4, 0,
+                                                         1.0 / 200.0, t, T, 1234, _lib.stream_ptr()))
+                agent.act_inplace(N)
+            agent.update(debug=True)
+        torch.cuda.synchronize()
+        res.append((agent.policy.flat.clone(), agent.last_loss.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.isfinite(res[0][1]).all()
