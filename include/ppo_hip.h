@@ -177,6 +177,17 @@ int ppo_cartpole_step(double* state, int* steps, unsigned* episodes, float* fin_
                       uint8_t* terminals_out, int64_t n_envs, int max_episode_steps, uint64_t seed,
                       void* stream);
 
+/* n_steps lockstep steps of the policy on the device-side CartPole envs, enqueued by one call: row t
+ * of the time-major buffers (states [n_steps*n_envs, 4], actions int32, logprobs, values, rewards,
+ * terminals) receives what ppo_act and ppo_cartpole_step produce at step t; obs_carry [n_envs, 4]
+ * holds the observation the policy sees first (in) and the one after the last step (out).
+ * The loop of train.py:173-183 for n_envs envs at once. */
+int ppo_cartpole_rollout(const float* params, double* state, int* steps, unsigned* episodes,
+                         float* fin_sum, int* fin_cnt, float* obs_carry, int64_t n_envs,
+                         int64_t n_steps, int max_episode_steps, uint64_t env_seed, uint64_t act_seed,
+                         uint64_t act_offset0, float* states, float* rewards, uint8_t* terminals,
+                         int* actions, float* logprobs, float* values, void* stream);
+
 /* Fused ppo_grad_reduce + ppo_adam_step for the single-process case (no all-reduce in between):
  * same arithmetic, one launch.  grad_out (P + 2 floats) still receives the reduced gradient. */
 int ppo_reduce_adam_step(int state_dim, int action_dim, const void* workspace, size_t workspace_bytes,

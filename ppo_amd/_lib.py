@@ -42,6 +42,9 @@ _SIGNATURES = {
                                    c_uint64, c_void_p]),
     "ppo_cartpole_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int64, c_int, c_uint64, c_void_p]),
+    "ppo_cartpole_rollout": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int64, c_int64, c_int, c_uint64, c_uint64, c_uint64, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppo_synth_rollout": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int64, c_int64, c_int,
                                   c_float, c_int64, c_int64, c_uint64, c_uint64, c_uint64, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

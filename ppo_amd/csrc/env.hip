@@ -114,3 +114,33 @@ extern "C" int ppo_cartpole_step(double* state, int* steps, unsigned* episodes, 
     cartpole_step_kernel<<<(int)((n_envs + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
     return (int)hipGetLastError();
 }
+
+// A whole lockstep rollout on the device, enqueued by one call: for t in [0, n_steps) the policy
+// acts on row t of the time-major buffers (ppo_act, rng_offset = act_offset0 + t) and the envs step
+// with those actions, writing reward/terminal into row t and the next observation into row t + 1
+// (into obs_carry after the last step).  Row 0 starts from obs_carry, i.e. from where the previous
+// rollout (or ppo_cartpole_reset) left the envs.  Same launches as the per-step calls.
+extern "C" int ppo_cartpole_rollout(const float* params, double* state, int* steps, unsigned* episodes,
+                                    float* fin_sum, int* fin_cnt, float* obs_carry, int64_t n_envs,
+                                    int64_t n_steps, int max_episode_steps, uint64_t env_seed,
+                                    uint64_t act_seed, uint64_t act_offset0, float* states,
+                                    float* rewards, uint8_t* terminals, int* actions, float* logprobs,
+                                    float* values, void* stream) {
+    if (!params || !obs_carry || !states || !rewards || !terminals || !actions || !logprobs || !values ||
+        n_envs <= 0 || n_steps <= 0)
+        return PPO_E_BADARG;
+    hipError_t e = hipMemcpyAsync(states, obs_carry, (size_t)n_envs * 4 * sizeof(float),
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    for (int64_t t = 0; t < n_steps; ++t) {
+        const size_t r0 = (size_t)t * n_envs;
+        int rc = ppo_act(params, 4, 2, 0, 0.f, states + r0 * 4, n_envs, act_seed, act_offset0 + t,
+                         actions + r0, logprobs + r0, values + r0, stream);
+        if (rc) return rc;
+        float* next_obs = t + 1 < n_steps ? states + (r0 + n_envs) * 4 : obs_carry;
+        rc = ppo_cartpole_step(state, steps, episodes, fin_sum, fin_cnt, actions + r0, next_obs,
+                               rewards + r0, terminals + r0, n_envs, max_episode_steps, env_seed, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -562,6 +562,29 @@ class PPO:
             b.rows("logprobs", lo, lo + n).data_ptr(), b.rows("state_values", lo, lo + n).data_ptr(),
             _lib.stream_ptr()))
 
+    def cartpole_rollout(self, env, n_steps):
+        """n_steps lockstep steps of this policy on a ppo_amd.envs.CartPoleVecEnv, all launches
+        enqueued by one C call (ppo_cartpole_rollout); equivalent to n_steps rounds of
+        next_state_slot / act_inplace / claim_env_slots / env.step."""
+        _require_gpu()
+        b = self.buffer
+        N = env.n_envs
+        n = N * n_steps
+        lo = b.claim_step(n)
+        b._n_envs = N
+        b._count["rewards"] += n
+        b._count["is_terminals"] += n
+        seed, off = self._next_rng()
+        self._rng_offset += n_steps - 1
+        _lib.check(_lib.lib().ppo_cartpole_rollout(
+            self.policy_old.flat.data_ptr(), env._state.data_ptr(), env._steps.data_ptr(),
+            env._episodes.data_ptr(), env.finished_return_sum.data_ptr(), env.finished_count.data_ptr(),
+            env._obs.data_ptr(), N, n_steps, env.max_episode_steps, env._seed, seed, off,
+            b.rows("states", lo, lo + n).data_ptr(), b.rows("rewards", lo, lo + n).data_ptr(),
+            b.rows("is_terminals", lo, lo + n).data_ptr(), b.rows("actions", lo, lo + n).data_ptr(),
+            b.rows("logprobs", lo, lo + n).data_ptr(), b.rows("state_values", lo, lo + n).data_ptr(),
+            _lib.stream_ptr()))
+
     def _act_rows(self, lo, n):
         b = self.buffer
         seed, off = self._next_rng()

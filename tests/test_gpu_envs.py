@@ -99,3 +99,38 @@ def test_train_synth_vectorised_learns_cartpole(envs, tmp_path):
     best = max(h[1] for h in history)
     assert first < 40.0
     assert best > 3.0 * first and best > 80.0, history
+
+
+def test_fused_cartpole_rollout_equals_per_step_calls(envs):
+    """ppo_cartpole_rollout leaves buffer, env state and episode statistics exactly as the per-step
+    in-place sequence does."""
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        from ppo_amd import ppo
+    N, T = 300, 40
+    cols = ("states", "actions", "logprobs", "state_values", "rewards", "is_terminals")
+    got = []
+    for fused in (True, False):
+        torch.manual_seed(5)
+        agent = ppo.PPO(4, 2, 3e-4, 1e-3, 0.99, 2, 0.2, False, None)
+        agent.buffer.reserve(N * T)
+        env = envs.CartPoleVecEnv(N)
+        env.max_episode_steps = 25                       # force time-limit resets too
+        env.seed(9)
+        obs = env.reset()
+        for _ in range(2):                               # two rollouts: the carry-over is exercised
+            if fused:
+                agent.cartpole_rollout(env, T)
+            else:
+                for _ in range(T):
+                    agent.next_state_slot(N).copy_(obs)
+                    actions = agent.act_inplace(N)
+                    r_row, d_row = agent.buffer.claim_env_slots(N)
+                    obs = env.step(actions, obs_out=obs, reward_out=r_row, done_out=d_row)[0]
+            snap = [agent.buffer.rows(c, 0, N * T).clone() for c in cols]
+            agent.update()
+        got.append(snap + [env._state.clone(), env._obs.clone(), env.finished_count.clone(),
+                           env.finished_return_sum.clone(), agent.policy.flat.clone()])
+    for i, (a, b) in enumerate(zip(*got)):
+        assert torch.equal(a, b), i

@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--inplace", action="store_true",
                     help="N > 1: let the env write rewards/terminals straight into the rollout buffer rows "
                          "(next_state_slot / act_inplace / claim_env_slots) instead of select_action + appends")
+    ap.add_argument("--fused-rollout", action="store_true",
+                    help="N > 1, CartPole: the whole rollout enqueued by one library call (ppo_cartpole_rollout)")
     ap.add_argument("--quiet", action="store_true")
     return ap.parse_args(argv)
 
@@ -140,7 +142,9 @@ def train(args):
         next_save = args.save_model_freq
         next_decay = args.action_std_decay_freq
         while time_step <= args.max_training_timesteps:
-            if args.inplace:
+            if args.fused_rollout:
+                agent.cartpole_rollout(env, H)
+            elif args.inplace:
                 for _ in range(H):
                     agent.next_state_slot(N).copy_(obs)
                     actions = agent.act_inplace(N)
