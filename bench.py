@@ -20,11 +20,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # BASELINE.json configs[3]: synthetic vectorised CartPole, 4096 envs/GPU x 128 steps
+    # the headline configuration: synthetic vectorised CartPole, 4096 envs/GPU x 128 steps
     "c4": dict(name="synthetic CartPole-shaped (S=4, A=2 discrete), {n_envs} envs/GPU x {horizon} steps, K={K}",
                S=4, A=2, continuous=False, std=None, n_envs=4096, horizon=128, K=80,
                reward_kind=0, p_terminal=1.0 / 200.0),
-    # BASELINE.json configs[4]: HalfCheetah-shaped continuous (obs 26, act 6), 65536 envs/GPU
+    # the large configuration: HalfCheetah-shaped continuous (obs 26, act 6), 65536 envs/GPU
     "c5": dict(name="synthetic HalfCheetah-shaped (S=26, A=6 continuous), {n_envs} envs/GPU x {horizon} steps, K={K}",
                S=26, A=6, continuous=True, std=0.6, n_envs=65536, horizon=128, K=80,
                reward_kind=1, p_terminal=-1.0),
