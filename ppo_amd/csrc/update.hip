@@ -82,13 +82,44 @@ __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 // ---------------------------------------------------------------------------- head + loss
 // Distribution head, PPO.py:233-240 loss terms and the gradient w.r.t. the head's inputs for one
 // sample per lane (both half-waves hold the same sample and compute the same values).
+// Per-sample inputs of the head, fetched at the top of the tile loop so that their global-memory
+// latency passes under the two MLP layers.
+template <int HEAD, int AOUT>
+struct HeadIn {
+    float ret, old_lp, adv;
+    int action;
+    float act[HEAD == HEAD_GAUSSIAN ? AOUT : 1];
+};
+
+template <int HEAD, int AOUT>
+__device__ __forceinline__ HeadIn<HEAD, AOUT> load_head_inputs(const FwdBwdArgs& a, int A, int64_t m,
+                                                               bool valid) {
+    HeadIn<HEAD, AOUT> in;
+    in.ret = 0.f; in.old_lp = 0.f; in.adv = 0.f; in.action = 0;
+    if constexpr (HEAD == HEAD_VALUE) {
+        in.ret = valid ? a.ret[m] : 0.f;
+    } else {
+        in.old_lp = valid ? a.old_logp[m] : 0.f;
+        in.adv = valid ? a.adv[m] : 0.f;
+        if constexpr (HEAD == HEAD_CATEGORICAL) {
+            in.action = valid ? reinterpret_cast<const int*>(a.actions)[m] : 0;
+        } else {
+            const float* ap = reinterpret_cast<const float*>(a.actions);
+#pragma unroll
+            for (int k = 0; k < AOUT; ++k) in.act[k] = (valid && k < A) ? ap[m * A + k] : 0.f;
+        }
+    }
+    return in;
+}
+
 template <int HEAD, int AOUT>
 __device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const float (&o)[AOUT],
+                                               const HeadIn<HEAD, AOUT>& in,
                                                int64_t m, bool valid, bool writer,
                                                float (&dout)[AOUT], double& loss_acc) {
     if constexpr (HEAD == HEAD_VALUE) {
         // 0.5 * MseLoss(state_values, rewards), PPO.py:240; d/dV of its mean = (V - R)/n
-        const float R = valid ? a.ret[m] : 0.f;
+        const float R = in.ret;
         const float diff = o[0] - R;
         dout[0] = valid ? diff * a.inv_n : 0.f;
         if (valid && writer) {
@@ -96,25 +127,21 @@ __device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const
             if (a.out_val) a.out_val[m] = o[0];
         }
     } else {
-        const float old_lp = valid ? a.old_logp[m] : 0.f;
-        const float adv = valid ? a.adv[m] : 0.f;
+        const float old_lp = in.old_lp;
+        const float adv = in.adv;
         float logp, ent;
         CatOut<AOUT> cat;
         GaussOut<AOUT> gs;
         int action = 0;
         if constexpr (HEAD == HEAD_CATEGORICAL) {
-            action = valid ? reinterpret_cast<const int*>(a.actions)[m] : 0;
+            action = in.action;
             categorical_head<AOUT>(o, A, cat);
             logp = cat.L[0];
 #pragma unroll
             for (int k = 1; k < AOUT; ++k) logp = (k == action) ? cat.L[k] : logp;
             ent = cat.ent;
         } else {
-            float act[AOUT];
-            const float* ap = reinterpret_cast<const float*>(a.actions);
-#pragma unroll
-            for (int k = 0; k < AOUT; ++k) act[k] = (valid && k < A) ? ap[m * A + k] : 0.f;
-            gaussian_head<AOUT>(o, A, a.action_var, act, gs);
+            gaussian_head<AOUT>(o, A, a.action_var, in.act, gs);
             logp = gs.logp;
             ent = gs.ent;
         }
@@ -241,6 +268,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         int ks1 = ks1_of(S), half_s = S >> 1;
         asm volatile("" : "+s"(ks1), "+s"(half_s));
         STAMP_START
+        const HeadIn<HEAD, AOUT> hin = load_head_inputs<HEAD, AOUT>(a, A, m, valid);
 
         // ---------------- layer 1 (bias rides as the ones column of X)
         f32x16 H1[2], H2[2];
@@ -267,7 +295,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
 
         // ---------------- head, loss, gradient w.r.t. the pre-head outputs
         float dout[AOUT];
-        head_loss_grad<HEAD, AOUT>(a, A, o, m, valid, h == 0, dout, loss_acc);
+        head_loss_grad<HEAD, AOUT>(a, A, o, hin, m, valid, h == 0, dout, loss_acc);
         if (h == 0) {
 #pragma unroll
             for (int k = 0; k < AOUT; ++k) gb3[k] += dout[k];
