@@ -35,7 +35,10 @@ VARIANTS = {
 def build():
     from ppo_amd import build as B
     os.makedirs(OUT, exist_ok=True)
-    for name, patches in VARIANTS.items():
+    variants = dict(VARIANTS)
+    if "--stamps" in sys.argv:      # the two single-role variants with per-phase cycle stamps
+        variants = {k + "_stamps": v for k, v in VARIANTS.items() if k in ("fwd_only", "bwd_only")}
+    for name, patches in variants.items():
         work = os.path.join("/tmp", "ppo_abl", name)
         shutil.rmtree(work, ignore_errors=True)
         shutil.copytree(B.CSRC, os.path.join(work, "ppo_amd", "csrc"))
@@ -49,7 +52,8 @@ def build():
             open(p, "w").write(new)
         srcs = [os.path.join(work, "ppo_amd", "csrc", s) for s in B.SOURCES]
         lib = os.path.join(OUT, f"libppo_hip_{name}.so")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-shared"] + srcs + ["-o", lib])
+        extra = ["-DPPO_PHASE_STAMPS"] if name.endswith("_stamps") else []
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + extra + ["-shared"] + srcs + ["-o", lib])
         print("built", lib, flush=True)
 
 

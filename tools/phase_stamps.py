@@ -14,7 +14,7 @@ import torch
 from bench import CONFIGS
 from ppo_amd import build as B
 
-LIB = os.path.join(ROOT, "ppo_amd", "libppo_hip_stamps.so")
+LIB = os.environ.get("PPO_STAMPS_LIB", os.path.join(ROOT, "ppo_amd", "libppo_hip_stamps.so"))
 if "--build" in sys.argv:
     srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DPPO_PHASE_STAMPS", "-shared"] + srcs + ["-o", LIB])
