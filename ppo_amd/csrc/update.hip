@@ -24,6 +24,7 @@
 // Nothing is accumulated with atomics: per-wave -> per-workgroup (fixed wave order through LDS) ->
 // ppo_grad_reduce (fixed workgroup order), so results are bit-reproducible run to run.
 #include "ppo_common.h"
+#include <cstdlib>
 
 #define FB_PAIRS 4
 #define FB_THREADS (FB_PAIRS * 2 * 64)
@@ -817,10 +818,12 @@ static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
 
 // Workgroups per role.  The actor's tiles cost more than the critic's (wider output layer, the
 // distribution head, for more than two outputs an extra MFMA weight gradient); measured ratios of
-// per-tile time are 1.09 (2 discrete actions) and 1.57 (6 continuous).  Depends on the action count
-// only, so every entry point derives the same split.
+// per-tile time (best split found by sweeping PPO_ACTOR_WGS) are 1.10 (2 discrete actions) and 1.37
+// (6 continuous).  Depends on the action count only, so every entry point derives the same split.
 static int actor_wgs(int A) {
-    const double r = 1.0 + (A > 2 ? 0.095 : 0.045) * A;
+    static const char* tune = getenv("PPO_ACTOR_WGS");   // tuning aid: fixed split for every shape
+    if (tune && atoi(tune) > 0 && atoi(tune) < FB_GRID) return atoi(tune);
+    const double r = 1.0 + (A > 2 ? 0.062 : 0.045) * A;
     int n = (int)(FB_GRID * r / (1.0 + r) + 0.5);
     return n < FB_GRID / 4 ? FB_GRID / 4 : (n > 3 * FB_GRID / 4 ? 3 * FB_GRID / 4 : n);
 }

@@ -47,7 +47,7 @@ fwd_names = ["L1 + tanh", "L2 + tanh", "out layer + head + L3 wgrad", "WAIT barr
              "dZ2 + hand-off writes", "WAIT barrier (written)", "epilogue"]
 bwd_names = ["xp loads issue", "WAIT barrier (free)", "WAIT barrier (written)", "dgrad", "dZ1 + transpose",
              "wgrad2", "wgrad1", "epilogue"]
-_r = 1.0 + (0.095 if A > 2 else 0.045) * A          # actor_wgs() of update.hip
+_r = 1.0 + (0.062 if A > 2 else 0.045) * A          # actor_wgs() of update.hip
 n_actor_wg = min(192, max(64, int(256 * _r / (1.0 + _r) + 0.5)))
 for role, sel in (("actor", slice(0, n_actor_wg)), ("critic", slice(n_actor_wg, 256))):
     for kind, ws, names in (("forward wave", slice(0, 4), fwd_names), ("backward wave", slice(4, 8), bwd_names)):
