@@ -195,6 +195,18 @@ int ppo_reduce_adam_step(int state_dim, int action_dim, const void* workspace, s
                          int64_t step, double lr_actor, double lr_critic, double beta1, double beta2,
                          double eps, float* loss_out, void* stream);
 
+/* The whole K-epoch loop of PPO.update (PPO.py:224-245) for a single process, enqueued by one
+ * call: k_epochs x (ppo_epoch_fwdbwd with n_global = n, ppo_reduce_adam_step with step
+ * first_step + e).  losses_out (may be NULL) receives k_epochs floats.  For small buffers (the
+ * reference's own 900-6000-step updates) the per-epoch cost is launch latency, which this halves. */
+int ppo_update_epochs(float* params, int state_dim, int action_dim, int continuous, float action_var,
+                      const float* states, const void* actions, const float* old_logprobs,
+                      const float* advantages, const float* returns_norm, int64_t n, float eps_clip,
+                      int k_epochs, float* grad_out, float* exp_avg, float* exp_avg_sq,
+                      int64_t first_step, double lr_actor, double lr_critic, double beta1,
+                      double beta2, double eps, float* losses_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to before d
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libppo_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _SIGNATURES = {
     "ppo_hip_abi_version": (c_int, []),
@@ -42,6 +42,10 @@ _SIGNATURES = {
                                    c_uint64, c_void_p]),
     "ppo_cartpole_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int64, c_int, c_uint64, c_void_p]),
+    "ppo_update_epochs": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_int64, c_double, c_double, c_double, c_double, c_double, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
     "ppo_cartpole_rollout": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int, c_uint64, c_uint64, c_uint64, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1000,7 +1000,31 @@ extern "C" int ppo_reduce_adam_step(int state_dim, int action_dim, const void* w
     return (int)hipGetLastError();
 }
 
-extern "C" int ppo_hip_abi_version(void) { return 2; }
+// The K-epoch loop of PPO.update (PPO.py:224-245) for one process: K x (ppo_epoch_fwdbwd,
+// ppo_reduce_adam_step) enqueued by one call; losses_out[e] receives loss.mean() of epoch e.
+extern "C" int ppo_update_epochs(float* params, int state_dim, int action_dim, int continuous,
+                                 float action_var, const float* states, const void* actions,
+                                 const float* old_logprobs, const float* advantages,
+                                 const float* returns_norm, int64_t n, float eps_clip, int k_epochs,
+                                 float* grad_out, float* exp_avg, float* exp_avg_sq, int64_t first_step,
+                                 double lr_actor, double lr_critic, double beta1, double beta2,
+                                 double eps, float* losses_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (k_epochs < 1 || first_step < 1) return PPO_E_BADARG;
+    for (int e = 0; e < k_epochs; ++e) {
+        int rc = ppo_epoch_fwdbwd(params, state_dim, action_dim, continuous, action_var, states, actions,
+                                  old_logprobs, advantages, returns_norm, n, n, eps_clip, nullptr,
+                                  nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        rc = ppo_reduce_adam_step(state_dim, action_dim, workspace, workspace_bytes, grad_out, params,
+                                  exp_avg, exp_avg_sq, first_step + e, lr_actor, lr_critic, beta1,
+                                  beta2, eps, losses_out ? losses_out + e : nullptr, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int ppo_hip_abi_version(void) { return 3; }
 
 extern "C" const char* ppo_hip_strerror(int code) {
     switch (code) {

@@ -650,7 +650,19 @@ class PPO:
                    for k in ("logprobs", "state_values", "entropy", "surrogate")}
         var32 = pol._var32()
         distributed = _dist.is_distributed()
-        for e in range(self.K_epochs):
+        per_epoch = distributed or debug or self.kernel_events is not None
+        if not per_epoch:
+            # single process: the whole epoch loop is one library call
+            g0, g1 = opt.param_groups
+            _lib.check(L.ppo_update_epochs(
+                pol.flat.data_ptr(), self.state_dim, self.action_dim, int(self.has_continuous_action_space),
+                var32, b.rows("states", 0, T).data_ptr(), b.rows("actions", 0, T).data_ptr(),
+                b.rows("logprobs", 0, T).data_ptr(), adv.data_ptr(), returns.data_ptr(), T,
+                float(self.eps_clip), self.K_epochs, opt.grad.data_ptr(), opt.exp_avg.data_ptr(),
+                opt.exp_avg_sq.data_ptr(), opt.step_count + 1, g0['lr'], g1['lr'], g0['betas'][0],
+                g0['betas'][1], g0['eps'], losses.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            opt.step_count += self.K_epochs
+        for e in range(self.K_epochs if per_epoch else 0):
             d = dbg if (dbg is not None and e == 0) else None
             if self.kernel_events is not None:
                 ev0 = torch.cuda.Event(enable_timing=True)

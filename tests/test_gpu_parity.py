@@ -318,18 +318,23 @@ def test_update_deterministic(eng):
 
 @pytest.mark.parametrize("name", ["c1_cartpole", "c3_bipedal"])
 def test_fused_reduce_adam_equals_two_launch(eng, name):
-    """ppo_reduce_adam_step (one launch) == ppo_grad_reduce + ppo_adam_step, bit for bit; the
-    debug=True update takes the two-launch path."""
+    """ppo_update_epochs (one call for all epochs) == per-epoch ppo_reduce_adam_step (one launch)
+    == ppo_grad_reduce + ppo_adam_step, bit for bit; kernel_events selects the per-epoch fused
+    path, debug=True the two-launch path."""
     ppo, _ = eng
     d = load_case(name)
     outs = []
-    for debug in (False, True):
+    for mode in ("one_call", "per_epoch", "two_launch"):
         agent = agent_from_case(ppo, d, 4)
-        agent.update(debug=debug)
+        if mode == "per_epoch":
+            agent.kernel_events = []
+        agent.update(debug=(mode == "two_launch"))
         outs.append((agent.policy.flat.clone(), agent.last_loss.clone(),
                      agent.optimizer.exp_avg.clone(), agent.optimizer.exp_avg_sq.clone()))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    assert agent.optimizer.step_count == 4
 
 
 @pytest.mark.parametrize("cont", [False, True])
