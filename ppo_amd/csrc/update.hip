@@ -14,7 +14,9 @@
 //                  w.r.t. the head inputs, dZ2 = (W3^T dout)(1 - H2^2); keeps the output layer's
 //                  and b2's gradient sums; hands dZ2 and H1 to its partner through LDS as
 //                  [sample][unit] rows (16-byte stores: four consecutive units per register quad);
-//   backward wave  dgrad dH1^T = W2^T dZ2^T, dZ1, and the two big weight gradients
+//   backward wave  dgrad dH1^T = W2^T dZ2^T, dZ1, and the two big weight gradients (the layer-1
+//                  one deferred until the hand-off buffers are released, so that its MFMAs run
+//                  under the forward wave's hand-off phase)
 //                  dW2 += dZ2^T H1, dW1 += dZ1^T [X 1], accumulated across all its tiles in MFMA
 //                  accumulator registers.
 // The orientation keeps the sample on the MFMA lane (ppo_common.h), so forward and dgrad chain
@@ -24,6 +26,7 @@
 // Nothing is accumulated with atomics: per-wave -> per-workgroup (fixed wave order through LDS) ->
 // ppo_grad_reduce (fixed workgroup order), so results are bit-reproducible run to run.
 #include "ppo_common.h"
+#include <cmath>
 #include <cstdlib>
 
 #define FB_PAIRS 4
@@ -37,7 +40,7 @@
 //   dtu  [9][DT_LD]   dout[a][m]  (MFMA output-layer wgrad only; row AOUT stays zero)
 #define DT_LD 36
 #define STG_MAT (TILE_M * W2_LD)
-#define STG_PAIR_FLOATS (2 * STG_MAT + 9 * DT_LD)
+#define STG_PAIR_FLOATS (2 * STG_MAT + 9 * DT_LD)   // (+ STG_MAT for the private dZ1 buffer when S <= 31)
 #define CS_LD 65                                       // row stride of colsum()'s scratch: odd => conflict-free
 
 // Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
@@ -75,6 +78,7 @@ struct FwdBwdArgs {
     float* partial_actor;   // [n_actor_wg][stride_actor]
     float* partial_critic;  // [FB_GRID - n_actor_wg][stride_critic]
     int n_actor_wg;         // workgroups 0 .. n_actor_wg-1 train the actor, the rest the critic
+    int* ws_header;         // [0] <- n_actor_wg: the reduction kernels read the split from here
     int stride_actor, stride_critic;
 };
 
@@ -211,6 +215,7 @@ struct WaveCtx {
     float* dzs;        // dZ2 [32][W2_LD], later dZ1
     float* h1s;        // H1  [32][W2_LD]
     float* dtu;        // dout [9][DT_LD]
+    float* dz1;        // dZ1 [32][W2_LD]: private to the backward wave (S <= 31), else aliases dzs
     float* red;        // [P.n + 1] workgroup reduction buffer (aliases the transposition space)
     int64_t tile0, tstride, n_tiles;
     int n_iter;        // same for every wave of the grid: the barriers match
@@ -478,15 +483,19 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     const float* const hcol = h1s + (16 * h) * W2_LD + c;
     const float* const zcoln = dzs + q4 * W2_LD + c16;               // narrow: k-step s <-> sample 4s + q4
 
-    for (int it = 0; it < ctx.n_iter; ++it) {
-        const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
-        const int64_t m0 = tile * TILE_M;
-        STAMP_START
+    // S <= 31: dZ1 has a buffer of its own, so the hand-off buffers are released BEFORE the layer-1
+    // wgrad runs: its MFMAs overlap with the forward wave's (latency-bound) hand-off phase of the
+    // next tile instead of preceding it.  Tile it-1's wgrad therefore runs inside iteration it.
+    constexpr bool DEFER = L1 < 2;
+    float* const z1row = ctx.dz1 + c * W2_LD + 4 * h;
+    const float* const z1col = ctx.dz1 + (16 * h) * W2_LD + c;
+    const float* const z1coln = ctx.dz1 + q4 * W2_LD + c16;
+    float xp[NARROW ? 1 : 16][JT];
+    float xq[NARROW ? 8 : 1];
+    auto load_x = [&](int64_t m0) {
         // B operands of the layer-1 wgrad, X_aug[sample][input] (1 at input S, 0 beyond), fetched
-        // before the barriers so that they are long there when needed (lines the partner loaded a
+        // ahead of the barriers so that they are long there when needed (lines the partner loaded a
         // tile ago).  Wide: xp[s][jt] = X_aug[16h+s][32*jt+c].  Narrow: xq[s] = X_aug[4s+q4][c16].
-        float xp[NARROW ? 1 : 16][JT];
-        float xq[NARROW ? 8 : 1];
         const bool full = m0 + TILE_M <= a.n;
         if constexpr (NARROW) {
             const float fill = c16 == S ? 1.0f : 0.0f;
@@ -529,9 +538,46 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                 }
             }
         }
+    };
+    auto wgrad1 = [&]() {
+        // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
+        if constexpr (NARROW) {
+            // v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+                    gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(z1coln[4 * s * W2_LD + 16 * t4],
+                                                                     xq[s], gW1n[t4], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float a0 = z1col[s * W2_LD];
+                const float a1 = z1col[s * W2_LD + 32];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
+                    gW1[1][jt] = mfma32(a1, xp[s][jt], gW1[1][jt]);
+                }
+            }
+        }
+    };
+
+    for (int it = 0; it < ctx.n_iter; ++it) {
+        const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
+        STAMP_START
+        if constexpr (DEFER) {
+            if (it > 0) load_x((tile - ctx.tstride) * TILE_M);   // operands of the deferred wgrad
+        } else {
+            load_x(tile * TILE_M);
+        }
         STAMP(0)
         __syncthreads();  // (forward wave: previous buffers may be overwritten)
         STAMP(1)
+        if constexpr (DEFER) {
+            if (it > 0) wgrad1();
+        }
         __syncthreads();  // buffers of this tile are complete
         STAMP(2)
 
@@ -576,8 +622,8 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
         }
         STAMP(5)
-        // ---------------- dZ1 takes dZ2's place (this wave's own reads of dZ2 are complete: LDS
-        // operations of one wave execute in order)
+        // ---------------- dZ1 goes to its own buffer (S <= 31) or takes dZ2's place (this wave's
+        // own reads of dZ2 are complete: LDS operations of one wave execute in order)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v0, v1;
@@ -586,32 +632,15 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                 v0[j] = d0[4 * q + j];
                 v1[j] = d1[4 * q + j];
             }
-            *reinterpret_cast<f32x4*>(zrow + 8 * q) = v0;
-            *reinterpret_cast<f32x4*>(zrow + 32 + 8 * q) = v1;
+            *reinterpret_cast<f32x4*>(z1row + 8 * q) = v0;
+            *reinterpret_cast<f32x4*>(z1row + 32 + 8 * q) = v1;
         }
-        // ---------------- wgrad of layer 1 (+ bias as the ones column): dW1[o, i] += dZ1[m, o] X[m, i]
-        if constexpr (NARROW) {
-            // v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4)
-                    gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(zcoln[4 * s * W2_LD + 16 * t4],
-                                                                     xq[s], gW1n[t4], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float a0 = zcol[s * W2_LD];
-                const float a1 = zcol[s * W2_LD + 32];
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    gW1[0][jt] = mfma32(a0, xp[s][jt], gW1[0][jt]);
-                    gW1[1][jt] = mfma32(a1, xp[s][jt], gW1[1][jt]);
-                }
-            }
-        }
+        if constexpr (!DEFER) wgrad1();
         STAMP(6)
+    }
+    if constexpr (DEFER) {  // the last tile's layer-1 wgrad
+        load_x((ctx.tile0 + (int64_t)(ctx.n_iter - 1) * ctx.tstride) * TILE_M);
+        wgrad1();
     }
     STAMP_START
 
@@ -668,9 +697,11 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     ctx.pair = wave & (FB_PAIRS - 1);
     ctx.L = carve_net_lds(smem, a.S, AOUT, true);
     float* stg = smem + round4(net_lds_floats(a.S, AOUT, true));
-    ctx.dzs = stg + ctx.pair * STG_PAIR_FLOATS;
+    constexpr int PAIR_FLOATS = STG_PAIR_FLOATS + (L1 < 2 ? STG_MAT : 0);
+    ctx.dzs = stg + ctx.pair * PAIR_FLOATS;
     ctx.h1s = ctx.dzs + STG_MAT;
     ctx.dtu = ctx.h1s + STG_MAT;
+    ctx.dz1 = L1 < 2 ? ctx.dtu + 9 * DT_LD : ctx.dzs;
     const int red_stride = ctx.P.n + 1;
     ctx.red = smem + ctx.pair * red_stride;  // valid once the tile loops are over
     ctx.n_tiles = (a.n + TILE_M - 1) / TILE_M;
@@ -679,7 +710,7 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     ctx.n_iter = (int)((ctx.n_tiles + ctx.tstride - 1) / ctx.tstride);
     fill_net_lds(ctx.L, a.params, ctx.P, a.S, ctx.A, AOUT, true);
     for (int i = threadIdx.x; i < FB_PAIRS * 9 * DT_LD; i += FB_THREADS)
-        stg[(i / (9 * DT_LD)) * STG_PAIR_FLOATS + 2 * STG_MAT + i % (9 * DT_LD)] = 0.f;
+        stg[(i / (9 * DT_LD)) * PAIR_FLOATS + 2 * STG_MAT + i % (9 * DT_LD)] = 0.f;
     __syncthreads();
 
     if (wave < FB_PAIRS) fwd_wave<HEAD, AOUT, L1>(a, ctx);
@@ -695,6 +726,7 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
 template <bool CONT, int AMAX, int L1>
 __global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs a) {
     extern __shared__ __align__(16) float smem[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ws_header[0] = a.n_actor_wg;
     if ((int)blockIdx.x < a.n_actor_wg)
         run_role<CONT ? HEAD_GAUSSIAN : HEAD_CATEGORICAL, AMAX, L1>(a, smem);
     else
@@ -706,12 +738,13 @@ __global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs 
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial_actor,
                                                           const float* __restrict__ partial_critic,
                                                           int stride_actor, int stride_critic,
-                                                          int n_actor, int n_critic, int rows_actor, int rows_critic,
+                                                          int n_actor, int n_critic, const int* __restrict__ ws_header,
                                                           float* __restrict__ grad) {
     __shared__ double part[4][64];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
     const int P = n_actor + n_critic;
+    const int rows_actor = ws_header[0], rows_critic = FB_GRID - rows_actor;
     double s = 0.0;
     if (i < P + 2) {
         const float* src;
@@ -758,7 +791,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ params,
 __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restrict__ partial_actor,
                                                           const float* __restrict__ partial_critic,
                                                           int stride_actor, int stride_critic,
-                                                          int n_actor, int n_critic, int rows_actor, int rows_critic,
+                                                          int n_actor, int n_critic, const int* __restrict__ ws_header,
                                                           float* __restrict__ grad,
                                                           float* __restrict__ params,
                                                           float* __restrict__ m, float* __restrict__ v,
@@ -772,6 +805,7 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
     const int P = n_actor + n_critic;
+    const int rows_actor = ws_header[0], rows_critic = FB_GRID - rows_actor;
     double s = 0.0;
     if (i < P + 2) {
         const float* src;
@@ -817,21 +851,38 @@ size_t ppo_scan_ws_bytes(int64_t n);  // scan.hip
 static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
 
 // Workgroups per role.  The actor's tiles cost more than the critic's (wider output layer, the
-// distribution head, for more than two outputs an extra MFMA weight gradient); measured ratios of
-// per-tile time (best split found by sweeping PPO_ACTOR_WGS) are 1.10 (2 discrete actions) and 1.37
-// (6 continuous).  Depends on the action count only, so every entry point derives the same split.
-static int actor_wgs(int A) {
+// distribution head, for more than two outputs an extra MFMA weight gradient): measured ratios r
+// of per-tile time are 1.14 (2 discrete actions) and 1.37 (6 continuous).  Every pair of a role
+// runs ceil(tiles / pairs) tiles, so the split minimises max(actor iterations * r, critic
+// iterations); at 524 288 samples that is 138 : 118 (30 and 35 iterations), at 8.4 M samples 148 : 108.
+// The fwd/bwd kernel leaves the split in the workspace header for the reduction kernels.
+#define FB_MAX_ROLE_WGS (3 * FB_GRID / 4)
+#define FB_WS_HEADER 256
+static int actor_wgs(int A, int64_t n) {
     static const char* tune = getenv("PPO_ACTOR_WGS");   // tuning aid: fixed split for every shape
-    if (tune && atoi(tune) > 0 && atoi(tune) < FB_GRID) return atoi(tune);
-    const double r = 1.0 + (A > 2 ? 0.062 : 0.045) * A;
-    int n = (int)(FB_GRID * r / (1.0 + r) + 0.5);
-    return n < FB_GRID / 4 ? FB_GRID / 4 : (n > 3 * FB_GRID / 4 ? 3 * FB_GRID / 4 : n);
+    if (tune && atoi(tune) >= FB_GRID - FB_MAX_ROLE_WGS && atoi(tune) <= FB_MAX_ROLE_WGS) return atoi(tune);
+    const double r = 1.0 + (A > 2 ? 0.062 : 0.072) * A;
+    const int64_t tiles = (n + TILE_M - 1) / TILE_M;
+    int best = FB_GRID / 2;
+    double best_cost = 1e300;
+    for (int na = FB_GRID - FB_MAX_ROLE_WGS; na <= FB_MAX_ROLE_WGS; ++na) {
+        const int64_t ia = (tiles + FB_PAIRS * na - 1) / (FB_PAIRS * na);
+        const int64_t ic = (tiles + FB_PAIRS * (FB_GRID - na) - 1) / (FB_PAIRS * (FB_GRID - na));
+        const double ca = ia * r, cc = (double)ic;
+        // ties (small buffers): prefer the split closest to the continuous optimum
+        const double cost = (ca > cc ? ca : cc) * (1.0 + 1e-6 * fabs(na - FB_GRID * r / (1.0 + r)));
+        if (cost < best_cost) { best_cost = cost; best = na; }
+    }
+    return best;
 }
 
+// [header | actor partials, FB_MAX_ROLE_WGS rows | critic partials, FB_MAX_ROLE_WGS rows]
+static size_t ws_critic_offset(int S, int A) {
+    return FB_WS_HEADER + align_up((size_t)FB_MAX_ROLE_WGS * stride_of(n_actor_params(S, A)) * sizeof(float), 256);
+}
 static size_t update_ws_bytes(int S, int A) {
-    const size_t na = actor_wgs(A), nc = FB_GRID - na;
-    return align_up(na * stride_of(n_actor_params(S, A)) * sizeof(float), 256) +
-           align_up(nc * stride_of(n_critic_params(S)) * sizeof(float), 256);
+    return ws_critic_offset(S, A) +
+           align_up((size_t)FB_MAX_ROLE_WGS * stride_of(n_critic_params(S)) * sizeof(float), 256);
 }
 
 extern "C" size_t ppo_workspace_bytes(int state_dim, int action_dim, int64_t max_samples) {
@@ -847,16 +898,16 @@ extern "C" int64_t ppo_param_count(int state_dim, int action_dim, int64_t* n_act
     return (int64_t)na + n_critic_params(state_dim);
 }
 
-static size_t fwdbwd_lds_bytes(int S, int A, int amax) {
+static size_t fwdbwd_lds_bytes(int S, int A, int amax, int l1) {
     const int net = round4(net_lds_floats(S, amax, true));
-    const int loop = net + FB_PAIRS * STG_PAIR_FLOATS;
+    const int loop = net + FB_PAIRS * (STG_PAIR_FLOATS + (l1 < 2 ? STG_MAT : 0));
     const int red = FB_PAIRS * (n_actor_params(S, A) + 1);  // the actor's arrays are the larger ones
     return (size_t)(loop > red ? loop : red) * sizeof(float);
 }
 
 template <bool CONT, int AMAX, int L1>
 static int launch_fwdbwd(const FwdBwdArgs& a, hipStream_t st) {
-    const size_t lds = fwdbwd_lds_bytes(a.S, a.A, AMAX);
+    const size_t lds = fwdbwd_lds_bytes(a.S, a.A, AMAX, L1);
     if (lds > 160 * 1024) return PPO_E_UNSUPPORTED;
     static size_t configured = 0;
     if (lds > configured) {
@@ -909,10 +960,10 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
     a.out_surr = out_surrogate;
     a.stride_actor = stride_of(n_actor_params(state_dim, action_dim));
     a.stride_critic = stride_of(n_critic_params(state_dim));
-    a.partial_actor = (float*)workspace;
-    a.n_actor_wg = actor_wgs(action_dim);
-    a.partial_critic = (float*)((char*)workspace +
-                                align_up((size_t)a.n_actor_wg * a.stride_actor * sizeof(float), 256));
+    a.ws_header = (int*)workspace;
+    a.partial_actor = (float*)((char*)workspace + FB_WS_HEADER);
+    a.n_actor_wg = actor_wgs(action_dim, n_local);
+    a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
     hipStream_t st = (hipStream_t)stream;
     const int l1 = state_dim + 1 <= 16 ? 0 : (state_dim + 1 <= 32 ? 1 : 2);
     const int amax = action_dim <= 2 ? 2 : (action_dim <= 4 ? 4 : 8);
@@ -939,12 +990,11 @@ extern "C" int ppo_grad_reduce(int state_dim, int action_dim, const void* worksp
     if (workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
     const int na = n_actor_params(state_dim, action_dim), nc = n_critic_params(state_dim);
     const int sa = stride_of(na), sc = stride_of(nc);
-    const float* pa = (const float*)workspace;
-    const float* pc = (const float*)((const char*)workspace +
-                                     align_up((size_t)actor_wgs(action_dim) * sa * sizeof(float), 256));
+    const float* pa = (const float*)((const char*)workspace + FB_WS_HEADER);
+    const float* pc = (const float*)((const char*)workspace + ws_critic_offset(state_dim, action_dim));
     const int total = na + nc + 2;
     grad_reduce_kernel<<<(total + 63) / 64, 256, 0, (hipStream_t)stream>>>(pa, pc, sa, sc, na, nc,
-                                                                          actor_wgs(action_dim), FB_GRID - actor_wgs(action_dim), grad_out);
+                                                                          (const int*)workspace, grad_out);
     return (int)hipGetLastError();
 }
 
@@ -987,13 +1037,12 @@ extern "C" int ppo_reduce_adam_step(int state_dim, int action_dim, const void* w
                              beta1, beta2, eps, loss_out, stream);
     }
     const int sa = stride_of(na), sc = stride_of(nc);
-    const float* pa = (const float*)workspace;
-    const float* pc = (const float*)((const char*)workspace +
-                                     align_up((size_t)actor_wgs(action_dim) * sa * sizeof(float), 256));
+    const float* pa = (const float*)((const char*)workspace + FB_WS_HEADER);
+    const float* pc = (const float*)((const char*)workspace + ws_critic_offset(state_dim, action_dim));
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
     reduce_adam_kernel<<<(P + 2 + 63) / 64, 256, 0, (hipStream_t)stream>>>(
-        pa, pc, sa, sc, na, nc, actor_wgs(action_dim), FB_GRID - actor_wgs(action_dim), grad_out, params,
+        pa, pc, sa, sc, na, nc, (const int*)workspace, grad_out, params,
         exp_avg, exp_avg_sq,
         (float)(-(lr_actor / bc1)), (float)(-(lr_critic / bc1)), (float)(1.0 - beta1), (float)beta2,
         (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, loss_out);

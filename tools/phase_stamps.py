@@ -47,8 +47,19 @@ fwd_names = ["L1 + tanh", "L2 + tanh", "out layer + head + L3 wgrad", "WAIT barr
              "dZ2 + hand-off writes", "WAIT barrier (written)", "epilogue"]
 bwd_names = ["xp loads issue", "WAIT barrier (free)", "WAIT barrier (written)", "dgrad", "dZ1 + transpose",
              "wgrad2", "wgrad1", "epilogue"]
-_r = 1.0 + (0.062 if A > 2 else 0.045) * A          # actor_wgs() of update.hip
-n_actor_wg = min(192, max(64, int(256 * _r / (1.0 + _r) + 0.5)))
+def actor_wgs(A, n):                                  # actor_wgs() of update.hip
+    r = 1.0 + (0.062 if A > 2 else 0.072) * A
+    tiles = (n + 31) // 32
+    best, best_cost = 128, 1e300
+    for na in range(64, 193):
+        ia, ic = -(-tiles // (4 * na)), -(-tiles // (4 * (256 - na)))
+        cost = max(ia * r, ic) * (1.0 + 1e-6 * abs(na - 256 * r / (1.0 + r)))
+        if cost < best_cost:
+            best, best_cost = na, cost
+    return best
+
+
+n_actor_wg = actor_wgs(A, N * T)
 for role, sel in (("actor", slice(0, n_actor_wg)), ("critic", slice(n_actor_wg, 256))):
     for kind, ws, names in (("forward wave", slice(0, 4), fwd_names), ("backward wave", slice(4, 8), bwd_names)):
         rows = st[sel][:, ws].reshape(-1, 16)
