@@ -210,6 +210,13 @@ __device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __res
     mlp_layer2(L, c, h, H1, H2);
 }
 
+// The value lane ^ 32 holds (v_permlane32_swap: a register move between the wave's halves, no LDS).
+__device__ __forceinline__ float other_half(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);  // r[0]: lower half's values, r[1]: upper half's
+}
+
 // o[a] = b3[a] + sum_u W3[a][u] * H2[u]; each lane sums its 32 units, the two halves are added.
 template <int AOUT>
 __device__ __forceinline__ void out_layer(const NetLds& L, int A, const f32x16 (&H2)[2], int h,
@@ -229,7 +236,7 @@ __device__ __forceinline__ void out_layer(const NetLds& L, int A, const f32x16 (
                     acc = fmaf(w.w, H2[t][4 * q + 3], acc);
                 }
             }
-            acc += __shfl_xor(acc, 32);
+            acc += other_half(acc);
             acc += L.b3[a];
         }
         o[a] = acc;
