@@ -244,6 +244,20 @@ __device__ __forceinline__ void out_layer(const NetLds& L, int A, const f32x16 (
 }
 
 // ------------------------------------------------------------------ heads
+// exp / log / divide of the distribution heads.  The heads are one dependent chain per sample (no
+// instruction-level parallelism to hide latencies), so they use the hardware's base-2 exp / log and
+// reciprocal (<= 1 ulp each) instead of the ~10-instruction correctly rounded library sequences;
+// -DPPO_HEAD_EXACT_MATH restores those.
+#ifdef PPO_HEAD_EXACT_MATH
+__device__ __forceinline__ float head_exp(float x) { return expf(x); }
+__device__ __forceinline__ float head_log(float x) { return logf(x); }
+__device__ __forceinline__ float head_div(float a, float b) { return a / b; }
+#else
+__device__ __forceinline__ float head_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float head_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float head_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
+
 // Categorical over softmax probabilities, restating torch/distributions/categorical.py:71
 // (renormalise), utils.py:121-137 (logits = log(clamp(probs, eps, 1-eps))), :150-161.
 template <int AOUT>
@@ -261,16 +275,16 @@ __device__ __forceinline__ void categorical_head(const float (&o)[AOUT], int A, 
     for (int a = 1; a < AOUT; ++a) if (a < A) mx = fmaxf(mx, o[a]);
     float e[AOUT], s = 0.f;
 #pragma unroll
-    for (int a = 0; a < AOUT; ++a) { e[a] = a < A ? expf(o[a] - mx) : 0.f; s += e[a]; }
+    for (int a = 0; a < AOUT; ++a) { e[a] = a < A ? head_exp(o[a] - mx) : 0.f; s += e[a]; }
     float s2 = 0.f;
 #pragma unroll
-    for (int a = 0; a < AOUT; ++a) { e[a] = e[a] / s; s2 += e[a]; }
+    for (int a = 0; a < AOUT; ++a) { e[a] = head_div(e[a], s); s2 += e[a]; }
     float ent = 0.f;
 #pragma unroll
     for (int a = 0; a < AOUT; ++a) {
-        const float q = e[a] / s2;
+        const float q = head_div(e[a], s2);
         const float qc = fminf(fmaxf(q, EPS_PROB_F), 1.0f - EPS_PROB_F);
-        const float L = logf(qc);
+        const float L = head_log(qc);
         out.q[a] = q;
         out.L[a] = L;
         out.pass[a] = (q >= EPS_PROB_F && q <= 1.0f - EPS_PROB_F) ? 1.f : 0.f;
@@ -298,7 +312,7 @@ __device__ __forceinline__ void gaussian_head(const float (&o)[AOUT], int A, flo
     for (int a = 0; a < AOUT; ++a) {
         if (a < A) {
             const float mu = tanh_f32(o[a]);
-            const float z = (act[a] - mu) / sigma;
+            const float z = head_div(act[a] - mu, sigma);
             out.mu[a] = mu;
             out.zed[a] = z;
             M += z * z;

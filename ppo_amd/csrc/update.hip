@@ -150,7 +150,7 @@ __device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const
             logp = gs.logp;
             ent = gs.ent;
         }
-        const float ratio = expf(logp - old_lp);
+        const float ratio = head_exp(logp - old_lp);
         const float s1 = ratio * adv;
         const float s2 = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi) * adv;
         const float surr = fminf(s1, s2);
@@ -178,7 +178,7 @@ __device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const
         } else {
 #pragma unroll
             for (int k = 0; k < AOUT; ++k)
-                dout[k] = k < A ? dlogp * (gs.zed[k] / gs.sigma) * (1.0f - gs.mu[k] * gs.mu[k]) : 0.f;
+                dout[k] = k < A ? dlogp * head_div(gs.zed[k], gs.sigma) * (1.0f - gs.mu[k] * gs.mu[k]) : 0.f;
         }
         if (valid && writer) {
             loss_acc += (double)(-surr - 0.01f * ent);
