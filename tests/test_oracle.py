@@ -133,3 +133,34 @@ def test_param_packing_roundtrip():
     Q = O.unflatten_params(flat, 8, 4)
     for k in O.PARAM_KEYS:
         assert np.array_equal(P[k], Q[k])
+
+
+# ------------------------------------------------------------------------------ CartPole restatement
+def test_cartpole_restatement_basic_properties():
+    """The CPU restatement of CartPole-v1 used to check the device env: reset range, determinism,
+    the known one-step response to a push from rest, random-policy episode lengths, time limit."""
+    from oracle import cartpole_oracle as C
+    env = C.VecCartPole(256, seed=5)
+    o = env.reset()
+    assert o.shape == (256, 4) and o.dtype == np.float32 and np.abs(o).max() < 0.05
+    assert np.array_equal(C.VecCartPole(256, seed=5).reset(), o)          # same seed, same start
+    assert not np.array_equal(C.VecCartPole(256, seed=6).reset(), o)
+    # from rest, a push to the right: x_dot += tau * F / (m_c + m_p) * (1 + small pole term), theta_dot < 0
+    s0 = np.zeros((1, 4))
+    s1, fell = C.step(s0, np.array([1]))
+    assert not fell[0] and s1[0, 0] == 0.0 and s1[0, 2] == 0.0
+    temp = 10.0 / 1.1
+    thacc = -temp / (0.5 * (4.0 / 3.0 - 0.1 / 1.1))
+    assert abs(s1[0, 3] - 0.02 * thacc) < 1e-15
+    assert abs(s1[0, 1] - 0.02 * (temp - 0.05 * thacc / 1.1)) < 1e-15
+    # a random policy keeps the pole up for roughly 10-100 steps on average (published behaviour: ~22)
+    rng = np.random.default_rng(0)
+    for t in range(400):
+        env.step(rng.integers(0, 2, 256))
+    mean_len = env.fin_sum.sum() / env.fin_cnt.sum()
+    assert 15.0 < mean_len < 30.0, mean_len
+    # time limit
+    short = C.VecCartPole(2, seed=1, max_steps=5)
+    short.reset()
+    dones = [short.step(np.array([t % 2, 1 - t % 2]))[2] for t in range(5)]
+    assert not np.any(dones[:4]) and np.all(dones[4])
