@@ -45,8 +45,8 @@ print("ms per launch:", [round(a.elapsed_time(b), 4) for a, b in agent.kernel_ev
 st = stamps.view(256, 8, 16).cpu().numpy().astype(float)
 fwd_names = ["L1 + tanh", "L2 + tanh", "out layer + head + L3 wgrad", "WAIT barrier (partner done)",
              "dZ2 + hand-off writes", "WAIT barrier (written)", "epilogue"]
-bwd_names = ["xp loads issue", "WAIT barrier (free)", "WAIT barrier (written)", "dgrad", "dZ1 + transpose",
-             "wgrad2", "wgrad1", "epilogue"]
+bwd_names = ["x loads issue", "WAIT barrier (release)", "deferred wgrad1 + WAIT barrier (written)", "dgrad",
+             "dZ1", "wgrad2", "dZ1 store (+ wgrad1 if S >= 32)", "epilogue"]
 def actor_wgs(A, n):                                  # actor_wgs() of update.hip
     r = 1.0 + (0.062 if A > 2 else 0.072) * A
     tiles = (n + 31) // 32
@@ -68,4 +68,4 @@ for role, sel in (("actor", slice(0, n_actor_wg)), ("critic", slice(n_actor_wg, 
         tiles = (N * T / 32) / (n_wg * 4)
         print(f"{role} {kind}: mean cycles/wave {tot:.0f} ({tot / tiles:.0f} per tile, {tiles:.1f} tiles/wave)")
         for i, nme in enumerate(names):
-            print(f"   {nme:30s} {rows[:, i].mean():10.0f}  {100 * rows[:, i].mean() / tot:5.1f}%  {rows[:, i].mean() / tiles:7.0f}/tile")
+            print(f"   {nme:42s} {rows[:, i].mean():10.0f}  {100 * rows[:, i].mean() / tot:5.1f}%  {rows[:, i].mean() / tiles:7.0f}/tile")
