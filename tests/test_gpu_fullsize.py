@@ -84,6 +84,24 @@ def test_full_size_gradient_matches_restatement_and_is_linear_over_shards(eng, S
     assert np.array_equal(g_again, g_full)
 
 
+@pytest.mark.parametrize("S,A,cont,T", [(1, 1, False, 777), (15, 5, False, 2050), (16, 1, True, 3001),
+                                        (31, 2, True, 2000), (32, 8, False, 1500), (40, 3, False, 5000),
+                                        (63, 8, True, 4099)])
+def test_every_shape_class_matches_restatement(eng, S, A, cont, T):
+    """One case per kernel instantiation class (layer-1 width classes at S = 15/16, 31/32 and the
+    maximum 63; head widths 1-2, 3-4, 5-8; both heads; buffer sizes that are not multiples of the
+    32-sample tile): per-sample outputs and the gradient against the CPU restatement."""
+    _, _lib = eng
+    P, x, acts, old, adv, ret, std = _problem(S, A, cont, T, 100 + S)
+    g, (lp, v, ent, surr) = _fwdbwd(_lib, P, S, A, cont, std, x, acts, old, adv, ret, 0, T, T, outs=True)
+    out_w, grads_w = O.ppo_loss_and_grads(P, x, acts, old, adv, ret, 0.2, cont, std)
+    assert rel_err(lp, out_w["logprobs"]) < 1e-5 and rel_err(v, out_w["state_values"]) < 1e-5
+    assert rel_err(ent, out_w["entropy"]) < 1e-5
+    want = O.flatten_params(grads_w)
+    assert max_abs(g[:-2], want) < 1e-4 * np.abs(want).max()
+    assert rel_err(g[-2] + g[-1], out_w["loss_mean"]) < 1e-5
+
+
 def test_full_size_iteration_equals_its_per_step_form(eng):
     """One benchmark iteration (C-side rollout loop + fused reduce/Adam) leaves exactly the state
     that the per-step public calls + the two-launch reduce/Adam leave."""
