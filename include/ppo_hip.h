@@ -101,7 +101,9 @@ int ppo_normalize_advantage(const float* returns, const float* old_values, int64
 
 /* ---- update --------------------------------------------------------------------------------
  * One epoch of evaluate + clipped-surrogate loss + backward over n_local samples, leaving
- * per-workgroup gradient partials in the workspace.  replaces: PPO.py:227-244 (evaluate, ratio,
+ * per-workgroup gradient partials in the workspace, preceded by a small header that records how the
+ * workgroups were split between actor and critic (the reduction functions read it back, so they
+ * have to be given the workspace of the preceding ppo_epoch_fwdbwd).  replaces: PPO.py:227-244 (evaluate, ratio,
  * surr1/surr2, loss, loss.mean().backward()).  Gradients are those of
  *   (1/n_global) * sum_t [ -min(r_t A_t, clamp(r_t,1-eps,1+eps) A_t) + 0.5 (V_t-R_t)^2 - 0.01 H_t ]
  * so that the sum over data-parallel shards is the reference's gradient.
