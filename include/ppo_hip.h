@@ -12,7 +12,9 @@
  *     parameter name ends in _host;
  *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*); nothing here
  *     synchronises, allocates or frees device memory;
- *   - thread-compatible, not thread-safe: one workspace per concurrent caller.
+ *   - thread-compatible, not thread-safe: one workspace per concurrent caller;
+ *   - one process drives ONE device (the data-parallel design is one process per GPU): the library
+ *     caches per-kernel launch attributes (dynamic LDS size) per process, not per device.
  *
  * Parameter vector layout (P floats, fp32, state_dict order of ActorCritic, PPO.py:49-73):
  *   actor.0.weight[64,S] actor.0.bias[64] actor.2.weight[64,64] actor.2.bias[64]
@@ -54,8 +56,10 @@ size_t ppo_workspace_bytes(int state_dim, int action_dim, int64_t max_samples);
  * Batched ActorCritic.act for n states at once.  replaces: PPO.py:86-100 (act) as called by
  * PPO.select_action, PPO.py:175-198.  Samples an action per state from Categorical(softmax) or
  * N(tanh(mean), diag(action_var)), and writes action, log-prob of that action, and the critic
- * value.  Randomness: Philox4x32-10 keyed by `seed`, counter (rng_offset, state index) - the
- * reference's action stream (torch global CPU generator) is not reproducible and not a parity
+ * value.  Randomness: Philox4x32-10 keyed by `seed`, counter (state index, rng_offset < 2^56, block):
+ * every (rng_offset, state index) pair owns a disjoint range of counter values, so the noise is
+ * independent across states, steps and action dimensions; data-parallel ranks pass different seeds.
+ * The reference's action stream (torch global CPU generator) is not reproducible and not a parity
  * target; log-prob and value for the (state, action) pairs written ARE.
  *   actions: int32[n] (discrete) or float[n, A] (continuous).
  *   action_var: fp32 value of std*std (PPO.py:46); ignored when continuous == 0.

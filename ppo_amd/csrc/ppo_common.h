@@ -328,12 +328,16 @@ __device__ __forceinline__ void gaussian_head(const float (&o)[AOUT], int A, flo
 }
 
 // ------------------------------------------------------------------ Philox4x32-10
+// 128-bit counter = (index: 64 bits | stream: 56 bits | block: 8 bits).  `index` is the sample / env,
+// `stream` the step (or episode) number, and successive next() calls of one generator advance only
+// `block`: the draws of different (stream, index) pairs never share a counter value, however many
+// blocks one of them consumes (at most 17 here: one block + 16 for a 63-dimensional observation).
 struct Philox {
     uint32_t c[4], k[2];
-    __device__ Philox(uint64_t seed, uint64_t ctr_hi, uint64_t ctr_lo) {
+    __device__ Philox(uint64_t seed, uint64_t stream, uint64_t index) {
         k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
-        c[0] = (uint32_t)ctr_lo; c[1] = (uint32_t)(ctr_lo >> 32);
-        c[2] = (uint32_t)ctr_hi; c[3] = (uint32_t)(ctr_hi >> 32);
+        c[0] = (uint32_t)index; c[1] = (uint32_t)(index >> 32);
+        c[2] = (uint32_t)stream; c[3] = (uint32_t)(stream >> 32) << 8;
     }
     __device__ void next(uint32_t (&out)[4]) {
         uint32_t x0 = c[0], x1 = c[1], x2 = c[2], x3 = c[3], k0 = k[0], k1 = k[1];
@@ -349,7 +353,7 @@ struct Philox {
             k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
         }
         out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
-        if (++c[0] == 0) if (++c[1] == 0) if (++c[2] == 0) ++c[3];
+        ++c[3];  // next block of this (stream, index)
     }
 };
 

@@ -263,11 +263,13 @@ __global__ __launch_bounds__(256) void moments_finalize(const Mom* __restrict__ 
 
 // PPO.py:212 (elementwise) + PPO.py:221.  fp32 arithmetic exactly as the reference's tensors:
 // mean and std are fp32 scalars, 1e-7 is added to the fp32 std, the division is IEEE.
-__global__ __launch_bounds__(256) void normalize_adv_kernel(const float* __restrict__ returns,
+// returns_norm may be the same buffer as returns (each thread reads an element before it writes
+// it), so neither of the two is declared __restrict__.
+__global__ __launch_bounds__(256) void normalize_adv_kernel(const float* returns,
                                                             const float* __restrict__ old_values,
                                                             int64_t n,
                                                             const double* __restrict__ moments,
-                                                            float* __restrict__ returns_norm,
+                                                            float* returns_norm,
                                                             float* __restrict__ adv) {
     const double cnt = moments[0];
     const float mean = (float)moments[1];

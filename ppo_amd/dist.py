@@ -19,6 +19,10 @@ def is_distributed():
     return td.is_available() and td.is_initialized() and td.get_world_size() > 1
 
 
+def rank():
+    return td.get_rank() if is_distributed() else 0
+
+
 def merge_moments_list(triples):
     """Chan et al. pairwise merge of (count, mean, M2) rows [W, 3] in row order (fp64)."""
     n, mean, m2 = triples[0, 0], triples[0, 1], triples[0, 2]

@@ -262,8 +262,10 @@ class ActorCritic(nn.Module):
         self.has_continuous_action_space = has_continuous_action_space
         self.state_dim = state_dim
         self.action_dim = action_dim
+        self._var_host = 0.0
         if has_continuous_action_space:
             self.action_var = torch.full((action_dim,), action_std_init * action_std_init).to(device)
+            self._var_host = float(np.float32(action_std_init * action_std_init))
         # same construction order as the reference so default init draws match under a seed
         head = nn.Tanh() if has_continuous_action_space else nn.Softmax(dim=-1)
         self.actor = nn.Sequential(nn.Linear(state_dim, 64), nn.Tanh(), nn.Linear(64, 64),
@@ -291,12 +293,19 @@ class ActorCritic(nn.Module):
         self.flat = flat
 
     def _apply(self, fn, recurse=True):
-        # .to(device) must not re-allocate the tensors and break the views
+        # The parameters are views into one flat fp32 vector on the engine's device; .to(device)
+        # as the reference calls it (PPO.py:138,144) is a no-op, and a conversion that would change
+        # dtype or device cannot be honoured (the kernels read that vector): refuse it loudly.
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self.flat.device))
+        if probe.dtype != torch.float32 or probe.device != self.flat.device:
+            raise RuntimeError("ppo_amd.ActorCritic holds fp32 parameters on the engine's device; "
+                               f"conversion to {probe.dtype} on {probe.device} is not supported")
         return self
 
     def set_action_std(self, new_action_std):
         if self.has_continuous_action_space:
             self.action_var = torch.full((self.action_dim,), new_action_std * new_action_std).to(device)
+            self._var_host = float(np.float32(new_action_std * new_action_std))
         else:
             print("--------------------------------------------------------------------------------------------")
             print("WARNING : Calling ActorCritic::set_action_std() on discrete action space policy")
@@ -306,7 +315,9 @@ class ActorCritic(nn.Module):
         raise NotImplementedError
 
     def _var32(self):
-        return float(self.action_var[0].item()) if self.has_continuous_action_space else 0.0
+        """fp32 value of std*std (what torch.full stores in action_var, PPO.py:46,77), kept on the
+        host so that no act / evaluate / update call has to read the device tensor back."""
+        return self._var_host
 
     def act(self, state, _seed=None, _offset=0, _out=None):
         """Batched ActorCritic.act (PPO.py:86-100): state [S] or [N, S] -> (action, logprob, value)."""
@@ -474,7 +485,11 @@ class PPO:
     # ------------------------------------------------------------------ rollout (PPO.py:175-198)
     def _next_rng(self):
         if self._rng_seed is None:
-            self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            # drawn from torch's generator (honours torch.manual_seed); data-parallel ranks seed torch
+            # identically to get identical initial weights, so the rank is folded into the Philox key:
+            # every rank's envs get their own noise streams
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._rng_seed = (seed ^ (_dist.rank() * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
         self._rng_offset += 1
         return self._rng_seed, self._rng_offset
 
@@ -567,6 +582,12 @@ class PPO:
         enqueued by one C call (ppo_cartpole_rollout); equivalent to n_steps rounds of
         next_state_slot / act_inplace / claim_env_slots / env.step."""
         _require_gpu()
+        if self.state_dim != 4 or self.action_dim != 2 or self.has_continuous_action_space:
+            raise ValueError("cartpole_rollout needs a discrete policy with state_dim 4 and action_dim 2 "
+                             f"(got {self.state_dim}, {self.action_dim}, continuous="
+                             f"{self.has_continuous_action_space})")
+        if not all(hasattr(env, a) for a in ("_state", "_steps", "_episodes", "_obs", "max_episode_steps")):
+            raise ValueError("cartpole_rollout needs a ppo_amd.envs.CartPoleVecEnv")
         b = self.buffer
         N = env.n_envs
         n = N * n_steps

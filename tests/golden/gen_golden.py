@@ -12,8 +12,9 @@ captured from the reference's own execution of ``PPO.select_action`` /
   * a wrapper around ``optimizer.step`` that records ``.grad`` before the step
     and Adam's state after it.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
-Output: tests/golden/*.npz, tests/golden/decay_sequence.json,
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [name ...]
+        (no names: everything; names select single outputs, e.g. ``c3_bipedal spread two_update``)
+Output: tests/golden/*.npz, tests/golden/decay_sequence.json, tests/golden/reference_spread.json,
         tests/golden/ckpt_*.pth (written by the reference's own ``save``).
 """
 import copy
@@ -336,18 +337,139 @@ def checkpoints():
     print("checkpoints: 6 envs")
 
 
-if __name__ == "__main__":
+def agent_from_arrays(d, K, order=None, returns_as_rewards=False):
+    """A reference agent rebuilt from a committed golden's INPUTS (initial weights + buffer), with
+    the buffer elements in the shapes the reference's own select_action stores (PPO.py:182-185).
+    order: optional permutation of the samples.  returns_as_rewards: the buffer's rewards are the
+    fp64 Monte-Carlo returns and every step is flagged terminal, so that PPO.py:202-208 reproduces
+    exactly those returns whatever the sample order."""
+    S, A, cont = int(d["S"]), int(d["A"]), bool(d["continuous"])
+    std = float(d["action_std"]) if cont else None
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ag = ref.PPO(S, A, float(d["lr_actor"]), float(d["lr_critic"]), float(d["gamma"]), K,
+                     float(d["eps_clip"]), cont, std)
+    sd = {k[len("param/"):]: torch.from_numpy(np.array(v)) for k, v in d.items() if k.startswith("param/")}
+    ag.policy.load_state_dict(sd)
+    ag.policy_old.load_state_dict(sd)
+    T = int(d["T"])
+    idx = np.arange(T) if order is None else np.asarray(order)
+    rewards = d["returns64"] if returns_as_rewards else d["rewards"]
+    for t in idx:
+        ag.buffer.states.append(torch.from_numpy(d["states"][t].copy()))
+        if cont:
+            ag.buffer.actions.append(torch.from_numpy(d["actions"][t].copy()).reshape(1, A))
+            ag.buffer.logprobs.append(torch.tensor([d["old_logprobs"][t]]))
+        else:
+            ag.buffer.actions.append(torch.tensor(int(d["actions"][t])))
+            ag.buffer.logprobs.append(torch.tensor(d["old_logprobs"][t]))
+        ag.buffer.state_values.append(torch.tensor([d["old_values"][t]]))
+        ag.buffer.rewards.append(float(rewards[t]))
+        ag.buffer.is_terminals.append(True if returns_as_rewards else bool(d["terminals"][t]))
+    return ag
+
+
+def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal")):
+    """How far the REFERENCE is from itself after K_cfg epochs on identical data when only the
+    order of its fp32 summations changes: (a) its update() under 8 intra-op threads instead of 1,
+    (b) its update() on the same samples in reversed order (rewards := the recorded returns, every
+    step terminal, so the return of each sample is unchanged).  Adam's first steps move every weight
+    by ~lr*sign(g); a gradient component near fp32 noise flips sign with the summation order, which
+    is what these numbers measure.  The K > 4 parameter tolerance of the tests is derived from them."""
+    out = {"torch_version": str(torch.__version__), "cases": {}}
+    for name in names:
+        z = np.load(os.path.join(HERE, name + ".npz"))
+        d = {k: z[k] for k in z.files}
+        K = int(d["K_list"][-1])
+        T = int(d["T"])
+        keys = [k[len("param/"):] for k in d if k.startswith("param/")]
+        want = {k: d[f"K{K}/param/{k}"] for k in keys}
+
+        def run(threads, **kw):
+            torch.set_num_threads(threads)
+            ag = agent_from_arrays(d, K, **kw)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ag.update()
+            torch.set_num_threads(1)
+            got = {k: v.numpy() for k, v in ag.policy.state_dict().items()}
+            return max(float(np.abs(got[k] - want[k]).max()) for k in keys)
+
+        same = run(1)                       # rebuilding the agent from the arrays reproduces the golden
+        assert same == 0.0, (name, same)
+        rec = {"K": K, "T": T,
+               "threads8": run(8),
+               "threads4": run(4),
+               "reversed_order": run(1, order=np.arange(T)[::-1], returns_as_rewards=True),
+               "returns_as_rewards_same_order": run(1, returns_as_rewards=True)}
+        rec["spread"] = max(rec["threads8"], rec["threads4"], rec["reversed_order"])
+        out["cases"][name] = rec
+        print("spread", name, rec)
+    with open(os.path.join(HERE, "reference_spread.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def two_update(name, S, A, T, K, continuous, std, rng_seed, decay=None):
+    """Two consecutive update() calls on ONE agent (update, refill with the new policy_old, update):
+    Adam's step count and moments persist across updates (PPO.py:139 is the only construction).
+    Records both rollouts as inputs and parameters + Adam state after each update; with `decay`
+    = (rate, min) the std schedule (PPO.py:159-173) runs between the two rollouts."""
+    rng = np.random.default_rng(rng_seed)
+    ag = make_agent(S, A, K, continuous, std, seed=rng_seed)
+    d = dict(S=S, A=A, T=T, K=K, continuous=continuous, action_std=np.float64(std or 0.0),
+             gamma=np.float64(0.99), eps_clip=np.float64(0.2), lr_actor=np.float64(3e-4),
+             lr_critic=np.float64(1e-3), torch_version=str(torch.__version__))
+    for k, v in ag.policy.state_dict().items():
+        d["param/" + k] = v.detach().cpu().numpy().copy()
+    for u in (1, 2):
+        fill_buffer(ag, S, T, rng, 1 / 100, "gauss")
+        for k, v in snapshot_inputs(ag, S, A, continuous).items():
+            if not k.startswith("param/"):
+                d[f"u{u}/{k}"] = v
+        d[f"u{u}/action_std"] = np.float64(ag.action_std if continuous else 0.0)
+        calls, evals, steps, names = run_update_recorded(ag)
+        for n, p in ag.policy.state_dict().items():
+            d[f"u{u}/after/param/{n}"] = p.numpy().copy()
+        for n, (m, v, st) in steps[-1][1].items():
+            d[f"u{u}/after/exp_avg/{n}"] = m
+            d[f"u{u}/after/exp_avg_sq/{n}"] = v
+            d[f"u{u}/after/step"] = np.float64(st)
+        means = [c for c in calls if c[0] == "mean"]
+        loss_calls = [c for c in means[1:] if np.ndim(c[1][0]) == 1 and c[1][0].shape[0] == T]
+        d[f"u{u}/loss_mean_all"] = np.asarray([c[2] for c in loss_calls], dtype=np.float32)
+        if u == 1 and decay is not None:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ag.decay_action_std(*decay)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: two updates of T={T} K={K} -> {os.path.getsize(path) / 1024:.0f} KiB, "
+          f"step={d['u2/after/step']}")
+
+
+TARGETS = {
     # C1 CartPole-shaped (train.py:19-48 defaults), C2 LunarLander-shaped, C3 BipedalWalker-shaped
-    case("c1_cartpole", 4, 2, 1600, [1, 4, 80], False, None, 1, p_term=1 / 100, reward_kind="one")
-    case("c2_lunarlander", 8, 4, 900, [1, 4, 30], False, None, 2)
-    case("c3_bipedal", 24, 4, 3000, [1, 4, 80], True, 0.6, 3, p_term=1 / 400)
-    case("c5_halfcheetah_small", 26, 6, 2048, [1, 4], True, 0.6, 4, p_term=0.0,
-         term_mask=(np.arange(2048) % 128 == 127))
+    # (update_timestep = 4 * max_ep_len = 6000, PPO_preTrained/README.md)
+    "c1_cartpole": lambda: case("c1_cartpole", 4, 2, 1600, [1, 4, 80], False, None, 1, p_term=1 / 100,
+                                reward_kind="one"),
+    "c2_lunarlander": lambda: case("c2_lunarlander", 8, 4, 900, [1, 4, 30], False, None, 2),
+    "c3_bipedal": lambda: case("c3_bipedal", 24, 4, 6000, [1, 4, 80], True, 0.6, 3, p_term=1 / 400),
+    "c5_halfcheetah_small": lambda: case("c5_halfcheetah_small", 26, 6, 2048, [1, 4], True, 0.6, 4,
+                                         p_term=0.0, term_mask=(np.arange(2048) % 128 == 127)),
     # edge cases
-    case("edge_a1_continuous", 3, 1, 257, [1, 4], True, 0.5, 5)
-    case("edge_offclip", 4, 2, 515, [1, 4], False, None, 6, logp_noise=0.6)
-    case("edge_saturated_softmax", 6, 3, 333, [1, 4], False, None, 8, weight_scale=60.0)
-    case("edge_std01", 5, 2, 130, [1, 2], True, 0.1, 9)
-    scan_cases()
-    decay_sequence()
-    checkpoints()
+    "edge_a1_continuous": lambda: case("edge_a1_continuous", 3, 1, 257, [1, 4], True, 0.5, 5),
+    "edge_offclip": lambda: case("edge_offclip", 4, 2, 515, [1, 4], False, None, 6, logp_noise=0.6),
+    "edge_saturated_softmax": lambda: case("edge_saturated_softmax", 6, 3, 333, [1, 4], False, None, 8,
+                                           weight_scale=60.0),
+    "edge_std01": lambda: case("edge_std01", 5, 2, 130, [1, 2], True, 0.1, 9),
+    "scan_cases": scan_cases,
+    "decay_sequence": decay_sequence,
+    "checkpoints": checkpoints,
+    # Adam state persisting over two update() calls; the continuous one decays the std in between
+    "two_update": lambda: (two_update("two_update_discrete", 4, 2, 700, 10, False, None, 21),
+                           two_update("two_update_continuous", 11, 3, 500, 8, True, 0.6, 22,
+                                      decay=(0.05, 0.1))),
+    "spread": reference_spread,       # after the cases it reads
+}
+
+if __name__ == "__main__":
+    for t in (sys.argv[1:] or list(TARGETS)):
+        TARGETS[t]()

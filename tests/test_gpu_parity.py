@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, UPDATE_CASES, case_params, load_case, max_abs, rel_err
+from helpers import (GOLDEN, TWO_UPDATE_CASES, UPDATE_CASES, case_params, load_case, max_abs,
+                     param_tolerance, rel_err)
 from oracle import ppo_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -214,6 +215,51 @@ def test_act_batched(eng, S, A, cont, N):
             assert np.abs(freq - p.mean(0)).max() < 0.05
 
 
+@pytest.mark.parametrize("A", [5, 6, 8])
+def test_act_noise_is_independent_across_envs_and_action_dims(eng, A):
+    """Every (step, env) owns its own Philox counter range: the Gaussian draw of env m in action
+    dims 4.. must not be the draw of env m+1 in dims 0.. (one generator block = 4 normals), and
+    adjacent envs / consecutive steps are uncorrelated."""
+    ppo, _ = eng
+    S, N = 7, 16384
+    torch.manual_seed(A)
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 1, 0.2, True, 0.6)
+    x = torch.randn(N, S, device="cuda")
+    P = {k: v.cpu().numpy() for k, v in agent.policy_old.state_dict().items()}
+    _, _, ao = O.mlp_forward(P, "actor", x.cpu().numpy())
+    mu = np.tanh(ao)
+    z = [(agent.select_action(x).cpu().numpy() - mu) / 0.6 for _ in range(2)]    # two steps, same states
+    corr = lambda a, b: float(np.corrcoef(a.reshape(-1), b.reshape(-1))[0, 1])
+    w = A - 4
+    assert np.abs(z[0][:-1, 4:] - z[0][1:, :w]).min() > 1e-6      # the old overlap made these equal
+    assert abs(corr(z[0][:-1, 4:], z[0][1:, :w])) < 0.03
+    assert abs(corr(z[0][:-1], z[0][1:])) < 0.03                    # adjacent envs
+    assert abs(corr(z[0], z[1])) < 0.03                             # consecutive steps
+    for a in range(A):
+        for b in range(a + 1, A):
+            assert abs(corr(z[0][:, a], z[0][:, b])) < 0.04         # action dims of one env
+    assert abs(z[0].mean()) < 0.02 and abs(z[0].std() - 1.0) < 0.02
+
+
+def test_synth_env_streams_do_not_overlap(eng):
+    """Reward/terminal block and observation blocks of adjacent synthetic envs are distinct draws."""
+    _, _lib = eng
+    N, S = 16384, 10
+    st = torch.empty(N, S, device="cuda")
+    r = torch.empty(N, device="cuda")
+    t = torch.empty(N, dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().ppo_synth_env_step(st.data_ptr(), r.data_ptr(), t.data_ptr(), N, S, 1, 0.1, 5, 128,
+                                             77, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    st, r = st.cpu().numpy(), r.cpu().numpy()
+    corr = lambda a, b: float(np.corrcoef(a.reshape(-1), b.reshape(-1))[0, 1])
+    assert np.abs(r[1:] - st[:-1, 0]).min() > 1e-7                  # was: reward[e+1] == state[e][0]
+    assert abs(corr(r[1:], st[:-1, 0])) < 0.03
+    assert abs(corr(st[:-1, 4:8], st[1:, 0:4])) < 0.03
+    assert abs(corr(st[:-1], st[1:])) < 0.03
+    assert abs(st.mean()) < 0.02 and abs(st.std() - 1.0) < 0.02
+
+
 def test_select_action_reference_surface(eng):
     ppo, _ = eng
     agent = ppo.PPO(4, 2, 3e-4, 1e-3, 0.99, 2, 0.2, False, None)
@@ -298,11 +344,52 @@ def test_update_k_epochs_golden(eng, name):
         torch.cuda.synchronize()
         got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
         worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
-        # K<=4: 1e-4.  K=30/80: fp32 summation-order noise amplified by Adam's sign-like early
-        # steps; torch-CPU vs numpy-CPU already differ by 1.2e-4 on the same data.
-        tol = TOL_PARAM if K <= 4 else 5e-4
-        assert worst < tol, (K, worst)
+        assert worst < param_tolerance(name, K), (K, worst)
         assert rel_err(agent.last_loss.cpu().numpy(), d[f"K{K}/loss_mean_all"]) < 1e-4, K
+        assert agent.optimizer.step_count == int(d[f"K{K}/step"])
+        if K <= 4:
+            check_adam_state(agent, lambda kind, k: d[f"K{K}/{kind}/{k}"], int(d["S"]), int(d["A"]))
+
+
+def check_adam_state(agent, want, S, A, tol=5e-4):
+    """exp_avg / exp_avg_sq of the engine's optimizer against the reference optimizer's state,
+    per tensor, relative to the tensor's largest entry (the gradients they average agree to
+    <= 1e-4 of the tensor's max; the second moment squares them)."""
+    m = O.unflatten_params(agent.optimizer.exp_avg.cpu().numpy(), S, A)
+    v = O.unflatten_params(agent.optimizer.exp_avg_sq.cpu().numpy(), S, A)
+    for k in O.PARAM_KEYS:
+        wm, wv = want("exp_avg", k), want("exp_avg_sq", k)
+        assert max_abs(m[k], wm) < tol * max(float(np.abs(wm).max()), 1e-30), ("exp_avg", k)
+        assert max_abs(v[k], wv) < tol * max(float(np.abs(wv).max()), 1e-30), ("exp_avg_sq", k)
+
+
+@pytest.mark.parametrize("name", TWO_UPDATE_CASES)
+def test_two_consecutive_updates_golden(eng, name):
+    """update, refill, update on one agent: Adam's step count and moments persist across update()
+    calls (PPO.py:139 is the optimizer's only construction); the continuous case decays the std in
+    between.  Parameters, exp_avg, exp_avg_sq and step against the reference after each update."""
+    ppo, _ = eng
+    d = load_case(name)
+    cont, K, S, A = bool(d["continuous"]), int(d["K"]), int(d["S"]), int(d["A"])
+    agent = ppo.PPO(S, A, float(d["lr_actor"]), float(d["lr_critic"]), float(d["gamma"]), K,
+                    float(d["eps_clip"]), cont, float(d["action_std"]) if cont else None)
+    sd = {k: torch.from_numpy(v) for k, v in case_params(d).items()}
+    agent.policy.load_state_dict(sd)
+    agent.policy_old.load_state_dict(sd)
+    for u in (1, 2):
+        if cont and float(d[f"u{u}/action_std"]) != agent.action_std:
+            agent.decay_action_std(0.05, 0.1)
+            assert agent.action_std == float(d[f"u{u}/action_std"])
+        agent.buffer.load_rollout(d[f"u{u}/states"], d[f"u{u}/actions"], d[f"u{u}/old_logprobs"],
+                                  d[f"u{u}/old_values"], d[f"u{u}/rewards"], d[f"u{u}/terminals"])
+        agent.update()
+        torch.cuda.synchronize()
+        assert agent.optimizer.step_count == int(d[f"u{u}/after/step"]) == u * K
+        got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
+        worst = max(max_abs(got[k], d[f"u{u}/after/param/{k}"]) for k in O.PARAM_KEYS)
+        assert worst < TOL_PARAM, (u, worst)
+        check_adam_state(agent, lambda kind, k: d[f"u{u}/after/{kind}/{k}"], S, A, tol=2e-3)
+        assert rel_err(agent.last_loss.cpu().numpy(), d[f"u{u}/loss_mean_all"]) < 1e-4
 
 
 def test_update_deterministic(eng):
@@ -438,6 +525,7 @@ def _dp_gpu_worker(rank, world, port, case, K, q):
     td.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     with contextlib.redirect_stdout(io.StringIO()):
         from ppo_amd import ppo
+    torch.manual_seed(0)                                  # as bench.py: identical seeding on every rank
     d = load_case(case)
     T = int(d["T"])
     cut = (T * 2) // 5                                   # uneven shards
@@ -449,6 +537,10 @@ def _dp_gpu_worker(rank, world, port, case, K, q):
     sd = {k: torch.from_numpy(v) for k, v in case_params(d).items()}
     agent.policy.load_state_dict(sd)
     agent.policy_old.load_state_dict(sd)
+    # identical states on both ranks: the sampled actions must still differ (rank folded into the key)
+    probe = torch.from_numpy(np.random.default_rng(0).standard_normal((256, int(d["S"]))).astype(np.float32))
+    probe_actions = agent.select_action(probe.cuda()).cpu().numpy()
+    agent.buffer.clear()
     # a shard must end at an episode boundary of the flat sequence for its scan to be independent:
     # scan the whole sequence with the oracle and hand each rank rewards that reproduce its slice
     ret64 = O.returns_scan(d["rewards"], d["terminals"], float(d["gamma"]))
@@ -461,7 +553,7 @@ def _dp_gpu_worker(rank, world, port, case, K, q):
                               d["old_values"][lo:hi], rew[lo:hi], term[lo:hi])
     agent.update()
     torch.cuda.synchronize()
-    q.put((rank, agent.policy.flat.cpu().numpy(), agent.last_loss.cpu().numpy()))
+    q.put((rank, agent.policy.flat.cpu().numpy(), agent.last_loss.cpu().numpy(), probe_actions))
     td.barrier()
     td.destroy_process_group()
 
@@ -485,6 +577,7 @@ def test_two_rank_update_equals_single_buffer(eng, case):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(res[0][1], res[1][1])          # replicas stay bit-identical
+    assert (res[0][3] != res[1][3]).mean() > 0.3          # but their exploration noise is not shared
     got = O.unflatten_params(res[0][1], int(d["S"]), int(d["A"]))
     worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
     assert worst < TOL_PARAM, worst
