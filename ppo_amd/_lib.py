@@ -9,7 +9,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint
 import torch  # noqa: F401  (loads the HIP runtime the library binds to before dlopen)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libppo_hip.so")
+# PPO_HIP_LIB: diagnostic builds of the same sources (python -m ppo_amd.build --variant ...)
+LIB_PATH = os.environ.get("PPO_HIP_LIB") or os.path.join(HERE, "libppo_hip.so")
 ABI_VERSION = 3
 
 _SIGNATURES = {

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
                 box_muller(u[2], u[3], e[2], e[3]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (a + j < AMAX) act[a + j] = tanh_f32(o[a + j]) + sigma * e[j];
+                    if (a + j < AMAX) act[a + j] = tanh_head(o[a + j]) + sigma * e[j];
             }
         } else {
 #pragma unroll

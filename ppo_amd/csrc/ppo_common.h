@@ -67,9 +67,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // 0.625) at ~3x the instructions.
 #define TANH_PRESCALE 2.8853900817779268f  // 2 * log2(e)
 
-__device__ __forceinline__ float tanh_prescaled(float xs) {  // xs = x * TANH_PRESCALE
-#ifdef PPO_TANH_ACCURATE
-    const float x = xs * (1.0f / TANH_PRESCALE);
+// <= 2.5 ulp: odd polynomial below 0.625, 1 - 2/(exp(2x)+1) above.
+__device__ __forceinline__ float tanh_accurate(float x) {
     const float z = x * x;
     float p = -5.70498872745e-3f;
     p = fmaf(p, z, 2.06390887954e-2f);
@@ -77,8 +76,13 @@ __device__ __forceinline__ float tanh_prescaled(float xs) {  // xs = x * TANH_PR
     p = fmaf(p, z, 1.33314422036e-1f);
     p = fmaf(p, z, -3.33332819422e-1f);
     const float small = fmaf(p * z, x, x);
-    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f);
+    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * TANH_PRESCALE) + 1.0f);
     return fabsf(x) < 0.625f ? small : fmaf(-2.0f, r, 1.0f);
+}
+
+__device__ __forceinline__ float tanh_prescaled(float xs) {  // xs = x * TANH_PRESCALE
+#ifdef PPO_TANH_ACCURATE
+    return tanh_accurate(xs * (1.0f / TANH_PRESCALE));
 #else
     const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f);
     return fmaf(-2.0f, r, 1.0f);
@@ -86,6 +90,18 @@ __device__ __forceinline__ float tanh_prescaled(float xs) {  // xs = x * TANH_PR
 }
 
 __device__ __forceinline__ float tanh_f32(float x) { return tanh_prescaled(x * TANH_PRESCALE); }
+
+// tanh of the Gaussian head's mean (PPO.py:55).  Unlike a hidden unit, whose error is averaged away
+// by the next layer's dot product, an error d in the mean reaches the log-prob multiplied by
+// (a - mu) / sigma^2 (up to ~5-30 for std 0.6-0.1): the head uses the accurate form (A <= 8 values
+// per sample, against 128 hidden units).  -DPPO_HEAD_TANH_FAST selects the 4-instruction form.
+__device__ __forceinline__ float tanh_head(float x) {
+#ifdef PPO_HEAD_TANH_FAST
+    return tanh_f32(x);
+#else
+    return tanh_accurate(x);
+#endif
+}
 
 __device__ __forceinline__ f32x16 tanh16_prescaled(f32x16 v) {
     f32x16 o;
@@ -311,7 +327,7 @@ __device__ __forceinline__ void gaussian_head(const float (&o)[AOUT], int A, flo
 #pragma unroll
     for (int a = 0; a < AOUT; ++a) {
         if (a < A) {
-            const float mu = tanh_f32(o[a]);
+            const float mu = tanh_head(o[a]);
             const float z = head_div(act[a] - mu, sigma);
             out.mu[a] = mu;
             out.zed[a] = z;

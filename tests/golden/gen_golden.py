@@ -369,13 +369,23 @@ def agent_from_arrays(d, K, order=None, returns_as_rewards=False):
     return ag
 
 
-def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal")):
-    """How far the REFERENCE is from itself after K_cfg epochs on identical data when only the
-    order of its fp32 summations changes: (a) its update() under 8 intra-op threads instead of 1,
-    (b) its update() on the same samples in reversed order (rewards := the recorded returns, every
-    step terminal, so the return of each sample is unchanged).  Adam's first steps move every weight
-    by ~lr*sign(g); a gradient component near fp32 noise flips sign with the summation order, which
-    is what these numbers measure.  The K > 4 parameter tolerance of the tests is derived from them."""
+def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal"), n_perm=40):
+    """What the REFERENCE itself produces after K_cfg epochs on identical data when only the order
+    of its fp32 summations changes: (a) its update() under 4 / 8 intra-op threads instead of 1,
+    (b) its update() on the same samples in reversed and in n_perm random orders (rewards := the
+    recorded returns, every step terminal, so the return of each sample is unchanged).
+    Every run is compared epoch by epoch with the golden run's parameter trajectory.  The runs
+    agree to a few 1e-5 for tens of epochs and then separate in discrete jumps onto a small number
+    of distinct end points ("branches": Adam normalises gradient rows that are at fp32 noise level
+    into lr-sized steps, so which side of zero / of an exact saturation a handful of terms falls on
+    decides whole weight rows).  Written:
+      reference_spread.json   per run: final distance from the golden run, first epoch > 1e-4 away;
+                              per case: diameter of the set of end points, number of branches;
+      <case>_branches.npz     the distinct end points (flat parameter vectors, 2e-5 apart or more):
+                              a correct implementation in another summation order must land within
+                              1e-4 of ONE of them;
+      <case>_traj.npz         the golden run's flat parameter vector after selected epochs, and per
+                              epoch the largest distance of any run from the golden run."""
     out = {"torch_version": str(torch.__version__), "cases": {}}
     for name in names:
         z = np.load(os.path.join(HERE, name + ".npz"))
@@ -383,27 +393,65 @@ def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal")):
         K = int(d["K_list"][-1])
         T = int(d["T"])
         keys = [k[len("param/"):] for k in d if k.startswith("param/")]
-        want = {k: d[f"K{K}/param/{k}"] for k in keys}
+        want = np.concatenate([d[f"K{K}/param/{k}"].reshape(-1) for k in keys])
 
         def run(threads, **kw):
             torch.set_num_threads(threads)
             ag = agent_from_arrays(d, K, **kw)
+            traj = []
+            orig = ag.optimizer.step
+
+            def step_wrap(*a, **k):
+                r = orig(*a, **k)
+                traj.append(torch.cat([p.detach().reshape(-1) for p in ag.policy.state_dict().values()])
+                            .numpy().copy())
+                return r
+
+            ag.optimizer.step = step_wrap
             with contextlib.redirect_stdout(io.StringIO()):
                 ag.update()
             torch.set_num_threads(1)
-            got = {k: v.numpy() for k, v in ag.policy.state_dict().items()}
-            return max(float(np.abs(got[k] - want[k]).max()) for k in keys)
+            return np.stack(traj)
 
-        same = run(1)                       # rebuilding the agent from the arrays reproduces the golden
-        assert same == 0.0, (name, same)
-        rec = {"K": K, "T": T,
-               "threads8": run(8),
-               "threads4": run(4),
-               "reversed_order": run(1, order=np.arange(T)[::-1], returns_as_rewards=True),
-               "returns_as_rewards_same_order": run(1, returns_as_rewards=True)}
-        rec["spread"] = max(rec["threads8"], rec["threads4"], rec["reversed_order"])
+        base = run(1)                       # rebuilding the agent from the arrays reproduces the golden
+        assert np.array_equal(base[-1], want), name
+        runs = {"threads4": run(4), "threads8": run(8),
+                "returns_as_rewards_same_order": run(1, returns_as_rewards=True),
+                "reversed_order": run(1, order=np.arange(T)[::-1], returns_as_rewards=True)}
+        rng = np.random.default_rng(1000 + T)
+        for i in range(n_perm):
+            runs[f"permutation{i}"] = run(1, order=rng.permutation(T), returns_as_rewards=True)
+        rec = {"K": K, "T": T, "runs": {}}
+        branches, counts = [base[-1]], [1]
+        curve = np.zeros(K)
+        for rn, tr in runs.items():
+            dev = np.abs(tr - base).max(axis=1)                     # per epoch
+            curve = np.maximum(curve, dev)
+            over = np.nonzero(dev > 1e-4)[0]
+            rec["runs"][rn] = {"final": float(dev[-1]),
+                               "first_epoch_over_1e-4": int(over[0]) + 1 if over.size else None,
+                               "max_over_first_4_epochs": float(dev[:4].max())}
+            dist = [float(np.abs(tr[-1] - b).max()) for b in branches]
+            if min(dist) > 2e-5:
+                branches.append(tr[-1])
+                counts.append(1)
+            else:
+                counts[int(np.argmin(dist))] += 1
+        assert rec["runs"]["returns_as_rewards_same_order"]["final"] == 0.0
+        rec["spread"] = max(r["final"] for r in rec["runs"].values())
+        fin = np.stack(branches)
+        rec["diameter"] = float(np.abs(fin[:, None, :] - fin[None, :, :]).max())
+        rec["n_branches"] = len(branches)
+        rec["branch_counts"] = counts
         out["cases"][name] = rec
-        print("spread", name, rec)
+        np.savez_compressed(os.path.join(HERE, name + "_branches.npz"), finals=fin,
+                            counts=np.asarray(counts))
+        snaps = sorted({k for k in (1, 2, 4, 8, 16, 24, 32, 48, 64, K) if k <= K})
+        # spread_curve[e-1]: largest distance of any of the runs above from the golden run after epoch e
+        np.savez_compressed(os.path.join(HERE, name + "_traj.npz"), epochs=np.asarray(snaps),
+                            spread_curve=curve, **{f"K{k}": base[k - 1] for k in snaps})
+        print("spread", name, {k: v for k, v in rec.items() if k != "runs"},
+              sorted(round(r["final"] * 1e4, 2) for r in rec["runs"].values()))
     with open(os.path.join(HERE, "reference_spread.json"), "w") as f:
         json.dump(out, f, indent=1)
 

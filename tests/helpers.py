@@ -1,5 +1,4 @@
 """Shared helpers for the parity tests."""
-import json
 import os
 
 import numpy as np
@@ -13,19 +12,22 @@ TWO_UPDATE_CASES = ["two_update_discrete", "two_update_continuous"]
 TOL_PARAM = 1e-4   # parameters after an update (north star)
 
 
-def param_tolerance(name, K):
-    """Bound on max |param - reference param| after K epochs.  Up to 4 epochs: 1e-4.  Beyond that
-    the reference is only defined up to its own summation-order spread: on identical data its
-    update() lands up to 1.2e-4 (C1, K=80) / 3.1e-4 (C3, K=80) away from itself when the intra-op
-    thread count or the sample order changes (reference_spread.json, recorded by gen_golden.py
-    from the reference's own runs), because Adam's early steps move a weight by ~lr*sign(g) and a
-    gradient component near fp32 noise flips sign with the order of the sum.  The bound for K > 4
-    is therefore 1e-4 + that recorded spread of the case."""
-    if K <= 4:
-        return TOL_PARAM
-    with open(os.path.join(GOLDEN, "reference_spread.json")) as f:
-        spread = json.load(f)["cases"]
-    return TOL_PARAM + float(spread[name]["spread"])
+def load_branches(name):
+    """End points of the reference's own update() on this case under re-ordered summations
+    (gen_golden.py: reference_spread): float32 [n_branches, P], flat state_dict order."""
+    return np.load(os.path.join(GOLDEN, name + "_branches.npz"))["finals"]
+
+
+def load_trajectory(name):
+    """Golden run's flat parameter vector after selected epochs + the reference's per-epoch spread."""
+    z = np.load(os.path.join(GOLDEN, name + "_traj.npz"))
+    return [int(k) for k in z["epochs"]], {int(k): z[f"K{int(k)}"] for k in z["epochs"]}, z["spread_curve"]
+
+
+def nearest_branch_distance(flat_params, name):
+    """max |param - reference end point| for the closest of the reference's recorded end points."""
+    fin = load_branches(name).astype(np.float64)
+    return float(np.abs(fin - np.asarray(flat_params, np.float64)[None, :]).max(axis=1).min())
 
 
 def load_case(name):

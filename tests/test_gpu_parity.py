@@ -8,14 +8,22 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (GOLDEN, TWO_UPDATE_CASES, UPDATE_CASES, case_params, load_case, max_abs,
-                     param_tolerance, rel_err)
+from helpers import (GOLDEN, TWO_UPDATE_CASES, UPDATE_CASES, case_params, load_case, load_trajectory,
+                     max_abs, nearest_branch_distance, rel_err)
 from oracle import ppo_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 TOL_REL = 1e-5     # returns / advantages / log-probs / loss (north star)
 TOL_PARAM = 1e-4   # parameters after an update
+
+# After more than a handful of epochs the reference's result is not a single point: on identical data
+# its own update() ends up to 1.5e-4 (C1, K=80) / 4.1e-4 (C3, K=80) away from its golden run when only
+# the order of its fp32 sums changes (intra-op threads, sample order), on a small number of distinct
+# end points (tests/golden/reference_spread.json, <case>_branches.npz, recorded by gen_golden.py from
+# the reference's own runs).  So for K > 4 the checks are: (1) within 1e-4 of the NEAREST recorded
+# end point of the reference, and (2) along the golden run's trajectory, within 1e-4 + the
+# reference's own spread at that epoch.  K <= 4 keeps the plain 1e-4 bound against the golden run.
 
 
 def tol_rel(name):
@@ -343,12 +351,29 @@ def test_update_k_epochs_golden(eng, name):
         agent.update()
         torch.cuda.synchronize()
         got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
-        worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
-        assert worst < param_tolerance(name, K), (K, worst)
+        if K <= 4:
+            worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
+        else:
+            worst = nearest_branch_distance(agent.policy.flat.cpu().numpy(), name)
+        assert worst < TOL_PARAM, (K, worst)
         assert rel_err(agent.last_loss.cpu().numpy(), d[f"K{K}/loss_mean_all"]) < 1e-4, K
         assert agent.optimizer.step_count == int(d[f"K{K}/step"])
         if K <= 4:
             check_adam_state(agent, lambda kind, k: d[f"K{K}/{kind}/{k}"], int(d["S"]), int(d["A"]))
+
+
+@pytest.mark.parametrize("name", ["c1_cartpole", "c2_lunarlander", "c3_bipedal"])
+def test_update_trajectory_within_reference_spread(eng, name):
+    """Parameters after 1, 2, 4, 8, ... epochs against the golden run's trajectory (one update()
+    per snapshot epoch count, each from the same initial state)."""
+    ppo, _ = eng
+    d = load_case(name)
+    epochs, snaps, curve = load_trajectory(name)
+    for K in epochs[:-1]:
+        agent = agent_from_case(ppo, d, K)
+        agent.update()
+        dev = max_abs(agent.policy.flat.cpu().numpy(), snaps[K])
+        assert dev < TOL_PARAM + float(curve[K - 1]), (K, dev)
 
 
 def check_adam_state(agent, want, S, A, tol=5e-4):

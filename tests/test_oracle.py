@@ -9,13 +9,21 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN, TWO_UPDATE_CASES, UPDATE_CASES, case_params, load_case, max_abs,
-                     param_tolerance, rel_err)
+from helpers import (GOLDEN, TWO_UPDATE_CASES, UPDATE_CASES, case_params, load_case, load_trajectory,
+                     max_abs, nearest_branch_distance, rel_err)
 from oracle import ppo_oracle as O
 
 # tolerances (north star: 1e-5 relative on returns/advantages/log-probs/loss, 1e-4 on params)
 TOL_REL = 1e-5
 TOL_PARAM = 1e-4
+
+# After more than a handful of epochs the reference's result is not a single point: on identical data
+# its own update() ends up to 1.5e-4 (C1, K=80) / 4.1e-4 (C3, K=80) away from its golden run when only
+# the order of its fp32 sums changes (intra-op threads, sample order), on a small number of distinct
+# end points (tests/golden/reference_spread.json, <case>_branches.npz, recorded by gen_golden.py from
+# the reference's own runs).  So for K > 4 the checks are: (1) within 1e-4 of the NEAREST recorded
+# end point of the reference, and (2) along the golden run's trajectory, within 1e-4 + the
+# reference's own spread at that epoch.  K <= 4 keeps the plain 1e-4 bound against the golden run.
 
 
 def _run(d, K, record=False):
@@ -64,8 +72,11 @@ def test_params_after_k_epochs(name):
     for K in d["K_list"][1:]:
         K = int(K)
         P, st, rec = _run(d, K)
-        worst = max(max_abs(P[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
-        assert worst < param_tolerance(name, K), (K, worst)
+        if K <= 4:
+            worst = max(max_abs(P[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
+        else:
+            worst = nearest_branch_distance(O.flatten_params(P), name)
+        assert worst < TOL_PARAM, (K, worst)
         assert rel_err(rec["loss_mean_all"], d[f"K{K}/loss_mean_all"]) < 1e-4
         assert st["step"] == int(d[f"K{K}/step"]) == K
         if K <= 4:   # Adam moments against the reference's optimizer state
@@ -73,6 +84,25 @@ def test_params_after_k_epochs(name):
                 m, v = d[f"K{K}/exp_avg/{k}"], d[f"K{K}/exp_avg_sq/{k}"]
                 assert max_abs(st["m"][k], m) < 1e-4 * max(float(np.abs(m).max()), 1e-30), k
                 assert max_abs(st["v"][k], v) < 1e-4 * max(float(np.abs(v).max()), 1e-30), k
+
+
+@pytest.mark.parametrize("name", ["c1_cartpole", "c2_lunarlander", "c3_bipedal"])
+def test_trajectory_within_reference_spread(name):
+    """Parameters after 1, 2, 4, 8, ... epochs against the golden run's trajectory."""
+    d = load_case(name)
+    epochs, snaps, curve = load_trajectory(name)
+    cont = bool(d["continuous"])
+    P = case_params(d)
+    st = O.adam_init(P)
+    ret64 = O.returns_scan(d["rewards"], d["terminals"], float(d["gamma"]))
+    _, _, _, ret_n = O.normalize_returns(ret64)
+    adv = (ret_n - d["old_values"]).astype(np.float32)
+    for e in range(1, epochs[-1] + 1):
+        _, grads = O.ppo_loss_and_grads(P, d["states"], d["actions"], d["old_logprobs"], adv, ret_n,
+                                        float(d["eps_clip"]), cont, float(d["action_std"]) if cont else None)
+        O.adam_step(P, grads, st, float(d["lr_actor"]), float(d["lr_critic"]))
+        if e in snaps and e < epochs[-1]:
+            assert max_abs(O.flatten_params(P), snaps[e]) < TOL_PARAM + float(curve[e - 1]), e
 
 
 @pytest.mark.parametrize("name", TWO_UPDATE_CASES)
