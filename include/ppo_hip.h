@@ -38,6 +38,7 @@ extern "C" {
 #define PPO_E_BADARG (-1)      /* shape / pointer / size outside what the kernels assume */
 #define PPO_E_WORKSPACE (-2)   /* workspace smaller than ppo_workspace_bytes() */
 #define PPO_E_UNSUPPORTED (-3) /* S or A beyond PPO_MAX_* */
+#define PPO_E_TOO_LARGE (-4)   /* size beyond the fixed capacity of an allocation-free entry point */
 
 /* ABI version of this header (bumped on any signature change). */
 int ppo_hip_abi_version(void);
@@ -86,6 +87,20 @@ int ppo_evaluate(const float* params, int state_dim, int action_dim, int continu
 int ppo_returns_scan_flat(const void* rewards, int rewards_are_f64, const uint8_t* terminals,
                           int64_t n, double gamma, float* returns_out, double* moments_out,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ppo_returns_scan_flat without a workspace argument and without any allocation.  No counterpart in
+ * the reference: it exists for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  The scan's scratch (block
+ * aggregates, carries, block moments) is a static device array inside the library, sized for
+ * n <= PPO_SCAN_NOALLOC_MAX (394 KB on every GPU the library runs on); larger n returns
+ * PPO_E_TOO_LARGE.  Results are identical to ppo_returns_scan_flat's, bit for bit.  Every call on
+ * one GPU uses that GPU's one array: calls that overlap in time on the same GPU (different
+ * streams or threads) race; calls on one stream, or on different GPUs, do not.  Nothing has to
+ * be cleared between calls. */
+#define PPO_SCAN_NOALLOC_MAX (1 << 24)
+int ppo_returns_scan_flat_noalloc(const void* rewards, int rewards_are_f64, const uint8_t* terminals,
+                                  int64_t n, double gamma, float* returns_out, double* moments_out,
+                                  void* stream);
 
 /* Same recurrence for a time-major [n_steps, n_envs] rollout of independent envs: column e is
  * env e's trajectory; a column starts from carry 0 at its last step exactly as the flat buffer

@@ -295,22 +295,13 @@ size_t ppo_scan_ws_bytes(int64_t n) {
            align_up(m * sizeof(Mom), 256);
 }
 
-extern "C" int ppo_returns_scan_flat(const void* rewards, int rewards_are_f64,
-                                     const uint8_t* terminals, int64_t n, double gamma,
-                                     float* returns_out, double* moments_out, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-    if (!rewards || !terminals || !returns_out || !moments_out || n <= 0 ||
-        n > ((int64_t)1 << 40))
-        return PPO_E_BADARG;
-    if (!workspace || workspace_bytes < ppo_scan_ws_bytes(n)) return PPO_E_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
+// The three launches of the flat scan + the moments merge, on scratch carved by the caller:
+// aff[nb + 1], carries[nb + 1], mom[nb + 1] with nb = ceil(n / SCAN_CHUNK).  Every entry a kernel
+// reads has been written by an earlier kernel of the same call: the scratch needs no clearing.
+static int launch_scan_flat(const void* rewards, int rewards_are_f64, const uint8_t* terminals,
+                            int64_t n, double gamma, float* returns_out, double* moments_out,
+                            Aff* aff, double* carries, Mom* mom, hipStream_t st) {
     const int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    char* w = (char*)workspace;
-    Aff* aff = (Aff*)w;
-    w += align_up((size_t)(nb + 1) * sizeof(Aff), 256);
-    double* carries = (double*)w;
-    w += align_up((size_t)(nb + 1) * sizeof(double), 256);
-    Mom* mom = (Mom*)w;
     if (rewards_are_f64) {
         scan_flat_reduce<double><<<nb, SCAN_BLOCK, 0, st>>>((const double*)rewards, terminals, n,
                                                             gamma, aff);
@@ -326,6 +317,65 @@ extern "C" int ppo_returns_scan_flat(const void* rewards, int rewards_are_f64,
     }
     moments_finalize<<<1, 256, 0, st>>>(mom, nb, moments_out);
     return (int)hipGetLastError();
+}
+
+extern "C" int ppo_returns_scan_flat(const void* rewards, int rewards_are_f64,
+                                     const uint8_t* terminals, int64_t n, double gamma,
+                                     float* returns_out, double* moments_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!rewards || !terminals || !returns_out || !moments_out || n <= 0 ||
+        n > ((int64_t)1 << 40))
+        return PPO_E_BADARG;
+    if (!workspace || workspace_bytes < ppo_scan_ws_bytes(n)) return PPO_E_WORKSPACE;
+    const int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    char* w = (char*)workspace;
+    Aff* aff = (Aff*)w;
+    w += align_up((size_t)(nb + 1) * sizeof(Aff), 256);
+    double* carries = (double*)w;
+    w += align_up((size_t)(nb + 1) * sizeof(double), 256);
+    Mom* mom = (Mom*)w;
+    return launch_scan_flat(rewards, rewards_are_f64, terminals, n, gamma, returns_out, moments_out,
+                            aff, carries, mom, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------- no-allocation variant
+// Same scan for callers that cannot allocate device memory (code under HIP graph capture, tight
+// serving loops): its block aggregates, carries and block moments live in a static device array
+// instead of a caller-provided workspace.  The array is sized for PPO_SCAN_NOALLOC_MAX elements
+// (394 KB, held by every GPU the library runs on until the process ends).  In host code the array's
+// name is only a stand-in for the symbol: its device address is looked up once per device with
+// hipGetSymbolAddress (each GPU holds its own copy) and only that address is handed to kernels.
+#define NOALLOC_NB ((PPO_SCAN_NOALLOC_MAX + SCAN_CHUNK - 1) / SCAN_CHUNK + 1)
+#define NOALLOC_AFF_BYTES ((NOALLOC_NB * sizeof(Aff) + 255) / 256 * 256)
+#define NOALLOC_CARRY_BYTES ((NOALLOC_NB * sizeof(double) + 255) / 256 * 256)
+#define NOALLOC_MOM_BYTES ((NOALLOC_NB * sizeof(Mom) + 255) / 256 * 256)
+static __device__ __align__(256) unsigned char scratch[NOALLOC_AFF_BYTES + NOALLOC_CARRY_BYTES + NOALLOC_MOM_BYTES];
+
+#define NOALLOC_MAX_DEVICES 64
+static void* scratch_addr[NOALLOC_MAX_DEVICES];  // device address of `scratch` per device, 0 = not looked up yet
+
+extern "C" int ppo_returns_scan_flat_noalloc(const void* rewards, int rewards_are_f64,
+                                             const uint8_t* terminals, int64_t n, double gamma,
+                                             float* returns_out, double* moments_out, void* stream) {
+    if (!rewards || !terminals || !returns_out || !moments_out || n <= 0) return PPO_E_BADARG;
+    if (n > (int64_t)PPO_SCAN_NOALLOC_MAX) return PPO_E_TOO_LARGE;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return PPO_E_BADARG;
+    if (!scratch_addr[dev]) {  // first call on this device (which is current)
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return PPO_E_BADARG;
+        scratch_addr[dev] = p;
+    }
+    char* w = (char*)scratch_addr[dev];
+    Aff* aff = (Aff*)w;
+    double* carries = (double*)(w + NOALLOC_AFF_BYTES);
+    Mom* mom = (Mom*)(w + NOALLOC_AFF_BYTES + NOALLOC_CARRY_BYTES);
+    return launch_scan_flat(rewards, rewards_are_f64, terminals, n, gamma, returns_out, moments_out,
+                            aff, carries, mom, (hipStream_t)stream);
 }
 
 extern "C" int ppo_returns_scan_rows(const float* rewards_tn, const uint8_t* terminals_tn,

@@ -1073,7 +1073,7 @@ extern "C" int ppo_update_epochs(float* params, int state_dim, int action_dim, i
     return 0;
 }
 
-extern "C" int ppo_hip_abi_version(void) { return 3; }
+extern "C" int ppo_hip_abi_version(void) { return 4; }
 
 extern "C" const char* ppo_hip_strerror(int code) {
     switch (code) {
@@ -1081,6 +1081,7 @@ extern "C" const char* ppo_hip_strerror(int code) {
         case PPO_E_BADARG: return "ppo_hip: bad argument (null pointer, non-positive size or inconsistent shape)";
         case PPO_E_WORKSPACE: return "ppo_hip: workspace missing or smaller than ppo_workspace_bytes()";
         case PPO_E_UNSUPPORTED: return "ppo_hip: state_dim or action_dim beyond PPO_MAX_STATE_DIM / PPO_MAX_ACTION_DIM";
+        case PPO_E_TOO_LARGE: return "ppo_hip: input larger than the fixed capacity of this allocation-free entry point (PPO_SCAN_NOALLOC_MAX elements)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ppo_hip: unknown error";
     }
 }
