@@ -6,8 +6,11 @@ on N GPUs of one node, weak scaling (fixed envs per GPU).
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
          --master-port 29511 bench.py --gpus 8 --steps 5 --warmup 2
+  python bench.py --config c1        # reference-shaped: one env, T single-state select_action calls + update()
 
-A "step" is one full iteration over one batch of synthetic input.  Rank 0 prints ONE JSON line.
+A "step" is one full iteration over one batch of synthetic input.  The timed loop runs the default
+product path (the calls a user of the PPO class makes); per-kernel times come from one extra,
+untimed, instrumented iteration afterwards.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -28,14 +31,45 @@ CONFIGS = {
     "c5": dict(name="synthetic HalfCheetah-shaped (S=26, A=6 continuous), {n_envs} envs/GPU x {horizon} steps, K={K}",
                S=26, A=6, continuous=True, std=0.6, n_envs=65536, horizon=128, K=80,
                reward_kind=1, p_terminal=-1.0),
+    # reference-shaped configurations: ONE env, the reference's per-step protocol (train.py:173-188):
+    # `horizon` single-state select_action calls with scalar reward / terminal appends, then update()
+    "c1": dict(name="CartPole-v1-shaped (S=4, A=2 discrete), 1 env x {horizon} steps per update, K={K}, "
+                    "single-state select_action protocol",
+               S=4, A=2, continuous=False, std=None, n_envs=1, horizon=1600, K=80,
+               reward_kind=0, p_terminal=1.0 / 200.0),
+    "c2": dict(name="LunarLander-v2-shaped (S=8, A=4 discrete), 1 env x {horizon} steps per update, K={K}, "
+                    "single-state select_action protocol",
+               S=8, A=4, continuous=False, std=None, n_envs=1, horizon=900, K=30,
+               reward_kind=1, p_terminal=1.0 / 300.0),
+    "c3": dict(name="BipedalWalker-v2-shaped (S=24, A=4 continuous, std 0.6), 1 env x {horizon} steps per "
+                    "update, K={K}, single-state select_action protocol",
+               S=24, A=4, continuous=True, std=0.6, n_envs=1, horizon=6000, K=80,
+               reward_kind=1, p_terminal=1.0 / 1500.0),
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X dense fp32 (vector = matrix) peak
 PEAK_HBM_GBS = 8000.0
+SCAN_BYTES_PER_STEP = 9        # fp32 reward + u8 terminal in, fp32 return out
+NORMALIZE_BYTES_PER_STEP = 16  # return + old value in, normalised return + advantage out
 
 
 def flops_per_sample_epoch(S, A):
     F = 2 * S * 64 + 2 * 64 * 64 + 64 * (A + 1)          # MACs of one actor+critic forward
     return 2 * (3 * F - 2 * S * 64)                      # fwd + wgrad + dgrad (no input gradient)
+
+
+def host_description(threads):
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    import torch
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(),
+            "torch_num_threads": torch.get_num_threads(), "blas_threads_used": threads}
 
 
 def cpu_baseline(cfg, threads):
@@ -47,7 +81,11 @@ def cpu_baseline(cfg, threads):
     rng = np.random.default_rng(0)
     shapes = O.param_shapes(S, A)
     P = {k: (rng.standard_normal(s) * 0.1).astype(np.float32) for k, s in shapes.items()}
-    Ts, n_act, n_ep = 524288, 150000, 16      # 10-15 s of CPU work on the GPU box's host cores
+    flat = cfg["n_envs"] == 1
+    if flat:     # the whole workload: T single-state act calls, scan + normalise, K epochs over T samples
+        Ts, n_act, n_ep = cfg["horizon"], cfg["horizon"], K
+    else:        # 10-15 s of CPU work on the GPU box's host cores, at the full buffer size
+        Ts, n_act, n_ep = 524288, 150000, 16
     x = rng.standard_normal((Ts, S)).astype(np.float32)
     acts = (rng.standard_normal((Ts, A)).astype(np.float32) if cont else rng.integers(0, A, Ts))
     with threadpool_limits(limits=threads):
@@ -71,25 +109,20 @@ def cpu_baseline(cfg, threads):
             O.adam_step(P, g, st, 3e-4, 1e-3)
         t_ep = (time.perf_counter() - t0) / (n_ep * Ts)
     per_step = t_act + t_scan + K * t_ep
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    import torch
+    sample = (f"numpy restatement, the whole workload once: {n_act} single-state act calls, scan+normalise "
+              f"of {Ts} steps, {n_ep} update epochs over {Ts} samples") if flat else \
+             (f"numpy restatement: {n_act} single-state act calls, scan+normalise of {Ts} "
+              f"steps, {n_ep} update epochs over {Ts} samples; extrapolated to K={K}")
     return {"value": 1.0 / per_step, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "host": {"cpu_model": model, "os_cpu_count": os.cpu_count(),
-                     "torch_num_threads": torch.get_num_threads(), "blas_threads_used": threads},
-            "sample": f"numpy restatement: {n_act} single-state act calls, scan+normalise of {Ts} "
-                      f"steps, {n_ep} update epochs over {Ts} samples; extrapolated to K={K}",
+            "host": host_description(threads), "sample": sample,
             "us_per_step": {"act": t_act * 1e6, "scan": t_scan * 1e6, "epoch": t_ep * 1e6}}
 
 
+_watchdog_file = None
+
+
 def main():
+    global _watchdog_file
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -106,7 +139,9 @@ def main():
     if args.n_envs:
         cfg["n_envs"] = args.n_envs
     cfg["name"] = cfg["name"].format(**cfg)
+    flat = cfg["n_envs"] == 1
 
+    import numpy as np
     import torch
     import torch.distributed as td
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,8 +149,10 @@ def main():
     if os.environ.get("PPO_BENCH_WATCHDOG"):     # rehearsal aid: dump the Python stacks of a stuck rank
         import faulthandler
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        faulthandler.dump_traceback_later(int(os.environ["PPO_BENCH_WATCHDOG"]), exit=True,
-                                          file=open(os.path.join(ROOT, "gpurun_out", f"watchdog_rank{rank}.txt"), "w"))
+        # the file object has to stay alive: faulthandler only holds its descriptor
+        _watchdog_file = open(os.path.join(ROOT, "gpurun_out", f"watchdog_rank{rank}.txt"), "w")
+        faulthandler.dump_traceback_later(int(os.environ["PPO_BENCH_WATCHDOG"]), exit=True, file=_watchdog_file)
+    grouped = world > 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one rank per GPU over RCCL; PPO_BENCH_BACKEND=gloo lets several ranks share one GPU to
@@ -128,23 +165,44 @@ def main():
             td.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             td.init_process_group(backend)
+    elif os.environ.get("PPO_BENCH_FORCE_GROUP") == "1":
+        # rehearsal: a one-rank RCCL group; with PPO_DIST_FORCE=1 the update takes the data-parallel path
+        torch.cuda.set_device(0)
+        td.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                              device_id=torch.device("cuda", 0))
+        grouped = True
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        from ppo_amd import _lib, ppo
-    L = _lib.lib()
+        from ppo_amd import ppo
     S, A, N, T, K = cfg["S"], cfg["A"], cfg["n_envs"], cfg["horizon"], cfg["K"]
     torch.manual_seed(0)                       # identical initial weights on every rank
     agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, K, 0.2, cfg["continuous"], cfg["std"])
     agent.buffer.reserve(N * T)
     env_seed = 1234 + rank
     it = [0]
+    host_rng = np.random.default_rng(env_seed)
+    if flat:    # the host-side "env" of the reference-shaped configurations: precomputed draws
+        flat_states = host_rng.standard_normal((T, S))                       # float64, as gym hands over
+        flat_rewards = [1.0] * T if cfg["reward_kind"] == 0 else host_rng.standard_normal(T).tolist()
+        flat_terms = (host_rng.random(T) < cfg["p_terminal"]).tolist()
+
+    def rollout():
+        if flat:
+            # the loop of train.py:173-181: one state in, one action out, scalar appends
+            b = agent.buffer
+            for t in range(T):
+                agent.select_action(flat_states[t])
+                b.rewards.append(flat_rewards[t])
+                b.is_terminals.append(flat_terms[t])
+        else:
+            # T lockstep steps: synthetic env step (obs, reward, terminal) then batched act on the N
+            # states, written straight into the device buffer
+            agent.synthetic_rollout(N, T, cfg["reward_kind"], cfg["p_terminal"], step0=it[0] * T,
+                                    env_seed=env_seed)
 
     def iteration(timed_phases=None):
-        # T lockstep steps: synthetic env step (obs, reward, terminal) then batched act on the N
-        # states, written straight into the device buffer; then the K-epoch update.
-        agent.synthetic_rollout(N, T, cfg["reward_kind"], cfg["p_terminal"], step0=it[0] * T,
-                                env_seed=env_seed)
+        rollout()
         if timed_phases is not None:
             torch.cuda.synchronize()
             timed_phases["rollout"] = time.perf_counter()
@@ -152,26 +210,25 @@ def main():
         it[0] += 1
 
     def barrier():
+        # drain this rank's device work, meet the other ranks, drain again (an RCCL barrier is itself
+        # device work on the current stream)
+        torch.cuda.synchronize()
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         iteration()
-    agent.kernel_events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         iteration()
     barrier()
     dt = time.perf_counter() - t0
-    events = agent.kernel_events
-    agent.kernel_events = None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
 
     # one more iteration with a host sync between phases, for the per-phase split (untimed)
     ph = {}
@@ -181,19 +238,44 @@ def main():
     torch.cuda.synchronize()
     p2 = time.perf_counter()
     phases = {"rollout_ms": (ph["rollout"] - p0) * 1e3, "update_ms": (p2 - ph["rollout"]) * 1e3}
+    if agent.last_dp_enqueue_s is not None:
+        # data-parallel path: host time spent enqueueing the K-epoch loop (launches + collectives)
+        phases["dp_host_enqueue_us_per_epoch"] = agent.last_dp_enqueue_s / K * 1e6
 
-    traffic = None
+    # one instrumented iteration (untimed): events on the launch stream around every fwd/bwd launch
+    # (this selects the per-epoch form of the same launches) and around the scan and normalise launches
+    agent.kernel_events = []
+    agent.phase_events = []
+    iteration()
+    torch.cuda.synchronize()
+    events, pev = agent.kernel_events, agent.phase_events
+    agent.kernel_events = agent.phase_events = None
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+    phase_ms = {name: a.elapsed_time(b) for name, a, b in pev}
+
+    traffic, traffic_source = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(args.config, {}).get("bytes_per_launch")
-        if args.n_envs or args.k_epochs:
-            traffic = None  # measured for the default shape only
+            rec = json.load(f).get(args.config, {})
+        if rec and not (args.n_envs or args.k_epochs):   # measured for the default shape only
+            traffic = rec.get("bytes_per_launch")
+            traffic_source = f"{rec.get('source')} (rocprofv3 --pmc passes of this workload, not measured by this run)"
     except OSError:
         pass
     if rank == 0:
-        steps_total = N * T * world * args.steps
-        flops_launch = flops_per_sample_epoch(S, A) * N * T
+        n = N * T
+        steps_total = n * world * args.steps
+        flops_launch = flops_per_sample_epoch(S, A) * n
         achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+        hbm = []
+        for name, kernel, bps in (("scan", "scan_flat_reduce/carries/apply + moments_finalize" if flat else
+                                   "scan_rows_kernel + moments_finalize", SCAN_BYTES_PER_STEP),
+                                  ("normalize", "normalize_adv_kernel", NORMALIZE_BYTES_PER_STEP)):
+            if name in phase_ms:
+                gbs = bps * n / (phase_ms[name] * 1e-3) / 1e9
+                hbm.append({"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": phase_ms[name],
+                            "bytes_per_step": bps})
         out = {
             "metric": "env-steps/sec (act+return scan+K-epoch update)",
             "value": steps_total / dt, "unit": "env-steps/s", "n_gpus": world,
@@ -205,16 +287,20 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "fwdbwd_kernel", "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "avg_launch_ms": kern_ms, "launches_timed": len(events),
-                         "flop_per_sample_epoch": flops_per_sample_epoch(S, A)},
+                         "flop_per_sample_epoch": flops_per_sample_epoch(S, A),
+                         "timed_in": "a separate instrumented iteration after the timed loop"},
+            "roofline_hbm_phases": hbm,
             "phases": phases,
             "final_loss": float(agent.last_loss[-1].item()),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        td.barrier()
+    if grouped:
+        if world > 1:
+            td.barrier()
         td.destroy_process_group()
 
 

@@ -11,12 +11,17 @@ that W shards reproduce the single-buffer update of PPO.py:200-251:
 Parameters and Adam state are replicated and stay bit-identical because every rank applies the
 same all-reduced gradient.
 """
+import os
+
 import torch
 import torch.distributed as td
 
 
 def is_distributed():
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    """More than one rank - or PPO_DIST_FORCE=1 on a one-rank group, which sends a single process
+    down the data-parallel code path (per-epoch reduce, all-reduce, Adam) for rehearsal and timing."""
+    return td.is_available() and td.is_initialized() and \
+        (td.get_world_size() > 1 or os.environ.get("PPO_DIST_FORCE") == "1")
 
 
 def rank():
@@ -38,9 +43,11 @@ def merge_moments_list(triples):
 
 def _stage_through_host(t):
     """gloo (the CPU backend the tests and single-GPU rehearsals use) gets host tensors: its
-    collectives on device tensors stage through the host anyway, and mixing them with host-side
-    barriers was seen to stall.  RCCL ("nccl") works on the device tensors directly."""
-    return t.is_cuda and td.get_backend() == "gloo"
+    collectives on device tensors stage through the host anyway, and with two ranks sharing one GPU
+    its all_reduce on a device tensor was seen never to complete (both ranks inside the same
+    all_reduce; stacks in profiles/r02_dp_rehearsal.txt).  RCCL ("nccl") works on the device tensors
+    directly.  PPO_DIST_GLOO_DEVICE=1 switches the staging off to reproduce that stall."""
+    return t.is_cuda and td.get_backend() == "gloo" and os.environ.get("PPO_DIST_GLOO_DEVICE") != "1"
 
 
 def merge_moments(moments):

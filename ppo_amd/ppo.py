@@ -13,6 +13,7 @@ batch of N lockstep envs per call: ``select_action(states[N, S])`` and tensor-va
 """
 import ctypes
 import os
+import time
 
 import numpy as np
 import torch
@@ -452,6 +453,8 @@ class PPO:
         self._ws = None
         self._moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.kernel_events = None  # set to a list to collect (start, end) CUDA events around every fwd/bwd launch
+        self.phase_events = None   # set to a list to collect (name, start, end) events around scan / normalise
+        self.last_dp_enqueue_s = None  # data-parallel path: host seconds spent enqueueing the last K-epoch loop
         self.last_loss = None      # device tensor [K_epochs]: loss.mean() of every epoch of the last update
         self.debug_outputs = None  # optional dict of per-sample first-epoch outputs (set by update(debug=True))
 
@@ -637,7 +640,17 @@ class PPO:
         returns = b.rows("returns", 0, T)
         adv = b.rows("advantages", 0, T)
 
+        def stamp(name=None, since=None):
+            if self.phase_events is None:
+                return None
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            if name is not None:
+                self.phase_events.append((name, since, ev))
+            return ev
+
         # Monte Carlo estimate of returns (PPO.py:202-211)
+        ev_scan = stamp()
         if host_rewards:
             if dev_rewards:
                 raise RuntimeError("mixing scalar and batched reward appends in one rollout is not supported")
@@ -655,11 +668,14 @@ class PPO:
                                                b.rows("is_terminals", 0, T).data_ptr(), T // n_envs, n_envs,
                                                float(self.gamma), returns.data_ptr(),
                                                self._moments.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        stamp("scan", ev_scan)
         # Normalizing the rewards (PPO.py:212) over ALL data-parallel shards, advantages (PPO.py:221)
         moments = _dist.merge_moments(self._moments)
         T_global = T if not _dist.is_distributed() else int(round(float(moments[0].item())))
+        ev_norm = stamp()
         _lib.check(L.ppo_normalize_advantage(returns.data_ptr(), b.rows("state_values", 0, T).data_ptr(), T,
                                              moments.data_ptr(), returns.data_ptr(), adv.data_ptr(), st))
+        stamp("normalize", ev_norm)
 
         # Optimize policy for K epochs (PPO.py:224-245)
         pol, opt = self.policy, self.optimizer
@@ -683,6 +699,7 @@ class PPO:
                 opt.exp_avg_sq.data_ptr(), opt.step_count + 1, g0['lr'], g1['lr'], g0['betas'][0],
                 g0['betas'][1], g0['eps'], losses.data_ptr(), ws.data_ptr(), ws.numel(), st))
             opt.step_count += self.K_epochs
+        t_loop = time.perf_counter()
         for e in range(self.K_epochs if per_epoch else 0):
             d = dbg if (dbg is not None and e == 0) else None
             if self.kernel_events is not None:
@@ -713,6 +730,7 @@ class PPO:
                 dbg["moments"] = moments.clone()
             opt.zero_grad()
             opt.step(loss_out=losses[e:e + 1])
+        self.last_dp_enqueue_s = (time.perf_counter() - t_loop) if distributed else None
         self.last_loss = losses
         self.debug_outputs = dbg
 
