@@ -39,65 +39,9 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
     out_layer<AMAX>(LA, A, H2, h, o);
 
     float logp, ent;
-    if constexpr (CONT) {
-        float act[AMAX];
-        float* ap = reinterpret_cast<float*>(actions_io);
-        if constexpr (SAMPLE) {
-            // MultivariateNormal.rsample: loc + scale_tril @ eps (multivariate_normal.py:250-253)
-            Philox rng(seed, rng_offset, (uint64_t)m);
-            const float sigma = sqrtf(action_var);
-#pragma unroll
-            for (int a = 0; a < AMAX; a += 4) {
-                uint32_t u[4];
-                rng.next(u);
-                float e[4];
-                box_muller(u[0], u[1], e[0], e[1]);
-                box_muller(u[2], u[3], e[2], e[3]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (a + j < AMAX) act[a + j] = tanh_head(o[a + j]) + sigma * e[j];
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) act[a] = (valid && a < A) ? ap[m * A + a] : 0.f;
-        }
-        GaussOut<AMAX> g;
-        gaussian_head<AMAX>(o, A, action_var, act, g);
-        logp = g.logp;
-        ent = g.ent;
-        if (SAMPLE && valid && h == 0) {
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) if (a < A) ap[m * A + a] = act[a];
-        }
-    } else {
-        CatOut<AMAX> cat;
-        categorical_head<AMAX>(o, A, cat);
-        int* ap = reinterpret_cast<int*>(actions_io);
-        int action;
-        if constexpr (SAMPLE) {
-            Philox rng(seed, rng_offset, (uint64_t)m);
-            uint32_t u[4];
-            rng.next(u);
-            const float uu = 1.0f - u01(u[0]);  // [0, 1)
-            float cum = 0.f;
-            action = A - 1;
-            bool done = false;
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                if (a < A) {
-                    cum += cat.q[a];
-                    if (!done && uu < cum) { action = a; done = true; }
-                }
-            }
-            if (valid && h == 0) ap[m] = action;
-        } else {
-            action = valid ? ap[m] : 0;
-        }
-        logp = cat.L[0];
-#pragma unroll
-        for (int a = 1; a < AMAX; ++a) logp = (a == action) ? cat.L[a] : logp;
-        ent = cat.ent;
-    }
+    int action;
+    policy_head_act<CONT, AMAX, SAMPLE>(o, A, action_var, seed, rng_offset, m, valid, h, actions_io, logp, ent,
+                                        action);
 
     if (valid && h == 0) {
         if (logprobs) logprobs[m] = logp;
@@ -186,54 +130,18 @@ __global__ __launch_bounds__(256) void synth_env_kernel(float* __restrict__ stat
                                                         int64_t horizon, uint64_t seed) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_envs) return;
-    Philox rng(seed ^ 0x9E3779B97F4A7C15ull, (uint64_t)step, (uint64_t)e);
-    uint32_t u[4];
-    rng.next(u);
-    float n0, n1;
-    box_muller(u[0], u[1], n0, n1);
-    if (rewards) rewards[e] = reward_kind == 0 ? 1.0f : n0;
-    if (terminals) {
-        bool t;
-        if (p_terminal < 0.f) t = (step % horizon) == horizon - 1;
-        else t = (1.0f - u01(u[2])) < p_terminal;
-        terminals[e] = t ? 1 : 0;
-    }
+    float reward;
+    bool term;
+    synth_env_reward_terminal(seed, step, e, reward_kind, p_terminal, horizon, reward, term);
+    if (rewards) rewards[e] = reward;
+    if (terminals) terminals[e] = term ? 1 : 0;
     if (states) {
         for (int k = 0; k < S; k += 4) {
-            rng.next(u);
             float v[4];
-            box_muller(u[0], u[1], v[0], v[1]);
-            box_muller(u[2], u[3], v[2], v[3]);
+            synth_env_state_block(seed, step, e, k >> 2, v);
             for (int j = 0; j < 4 && k + j < S; ++j) states[e * S + k + j] = v[j];
         }
     }
-}
-
-extern "C" int ppo_synth_env_step(float* states_out, float* rewards_out, uint8_t* terminals_out,
-                                  int64_t n_envs, int state_dim, int reward_kind, float p_terminal,
-                                  int64_t step, int64_t horizon, uint64_t seed, void* stream);
-
-extern "C" int ppo_synth_rollout(const float* params, int state_dim, int action_dim, int continuous,
-                                 float action_var, int64_t n_envs, int64_t n_steps, int reward_kind,
-                                 float p_terminal, int64_t step0, int64_t horizon, uint64_t env_seed,
-                                 uint64_t act_seed, uint64_t act_offset0, float* states, float* rewards,
-                                 uint8_t* terminals, void* actions, float* logprobs, float* values,
-                                 void* stream) {
-    if (n_steps <= 0 || n_envs <= 0) return PPO_E_BADARG;
-    const size_t arow = continuous ? (size_t)action_dim * sizeof(float) : sizeof(int);
-    for (int64_t t = 0; t < n_steps; ++t) {
-        const size_t r0 = (size_t)t * n_envs;
-        int rc = ppo_synth_env_step(states + r0 * state_dim, rewards + r0, terminals + r0, n_envs,
-                                    state_dim, reward_kind, p_terminal, step0 + t, horizon, env_seed,
-                                    stream);
-        if (rc) return rc;
-        rc = launch_act<true>(params, state_dim, action_dim, continuous, action_var,
-                              states + r0 * state_dim, n_envs, act_seed, act_offset0 + t,
-                              (char*)actions + r0 * arow, logprobs + r0, values + r0, nullptr,
-                              (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    return 0;
 }
 
 extern "C" int ppo_synth_env_step(float* states_out, float* rewards_out, uint8_t* terminals_out,

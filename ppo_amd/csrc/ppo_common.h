@@ -69,6 +69,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 // <= 2.5 ulp: odd polynomial below 0.625, 1 - 2/(exp(2x)+1) above.
 __device__ __forceinline__ float tanh_accurate(float x) {
+#pragma clang fp contract(off)
     const float z = x * x;
     float p = -5.70498872745e-3f;
     p = fmaf(p, z, 2.06390887954e-2f);
@@ -206,16 +207,16 @@ __device__ __forceinline__ void mlp_layer2(const NetLds& L, int c, int h, const 
 }
 
 // ------------------------------------------------------------------ forward of one 32-sample tile
-// states: [n, S] row-major; m = this lane's sample; valid = m < n.
-__device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __restrict__ states,
-                                             int S, int64_t m, bool valid, int c, int h,
-                                             f32x16 (&H1)[2], f32x16 (&H2)[2]) {
+// x(k) returns input k (< S) of this lane's sample (0 for a lane without a sample).
+template <class X>
+__device__ __forceinline__ void mlp_fwd_tile_x(const NetLds& L, int S, const X& x, int c, int h,
+                                               f32x16 (&H1)[2], f32x16 (&H2)[2]) {
     f32x16 z0 = {0}, z1 = {0};
     const int ks1 = ks1_of(S);
     for (int s = 0; s < ks1; ++s) {
         const int k = 2 * s + h;
         float b = (k == S) ? 1.0f : 0.0f;          // ones column carries the bias
-        if (k < S && valid) b = states[m * S + k];
+        if (k < S) b = x(k);
         const float a0 = L.w1t[k * HID + c];
         const float a1 = L.w1t[k * HID + 32 + c];
         z0 = mfma32(a0, b, z0);
@@ -224,6 +225,27 @@ __device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __res
     H1[0] = tanh16_prescaled(z0);
     H1[1] = tanh16_prescaled(z1);
     mlp_layer2(L, c, h, H1, H2);
+}
+
+struct RowFromGlobal {  // states: [n, S] row-major; m = this lane's sample; valid = m < n
+    const float* __restrict__ states;
+    int S;
+    int64_t m;
+    bool valid;
+    __device__ __forceinline__ float operator()(int k) const { return valid ? states[m * S + k] : 0.f; }
+};
+
+struct RowFromLds {  // this lane's sample row in an LDS staging tile
+    const float* row;
+    bool valid;
+    __device__ __forceinline__ float operator()(int k) const { return valid ? row[k] : 0.f; }
+};
+
+__device__ __forceinline__ void mlp_fwd_tile(const NetLds& L, const float* __restrict__ states,
+                                             int S, int64_t m, bool valid, int c, int h,
+                                             f32x16 (&H1)[2], f32x16 (&H2)[2]) {
+    const RowFromGlobal x{states, S, m, valid};
+    mlp_fwd_tile_x(L, S, x, c, h, H1, H2);
 }
 
 // The value lane ^ 32 holds (v_permlane32_swap: a register move between the wave's halves, no LDS).
@@ -260,6 +282,9 @@ __device__ __forceinline__ void out_layer(const NetLds& L, int A, const f32x16 (
 }
 
 // ------------------------------------------------------------------ heads
+// The head functions below switch floating-point contraction off: every multiply and add is
+// rounded as written, so the same (state, action) gives bit-identical log-probs in every kernel
+// that inlines them (per-step act, fused rollout, evaluate, update), whatever the surrounding code.
 // exp / log / divide of the distribution heads.  The heads are one dependent chain per sample (no
 // instruction-level parallelism to hide latencies), so they use the hardware's base-2 exp / log and
 // reciprocal (<= 1 ulp each) instead of the ~10-instruction correctly rounded library sequences;
@@ -269,9 +294,18 @@ __device__ __forceinline__ float head_exp(float x) { return expf(x); }
 __device__ __forceinline__ float head_log(float x) { return logf(x); }
 __device__ __forceinline__ float head_div(float a, float b) { return a / b; }
 #else
-__device__ __forceinline__ float head_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-__device__ __forceinline__ float head_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
-__device__ __forceinline__ float head_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float head_exp(float x) {
+#pragma clang fp contract(off)
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+__device__ __forceinline__ float head_log(float x) {
+#pragma clang fp contract(off)
+    return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+}
+__device__ __forceinline__ float head_div(float a, float b) {
+#pragma clang fp contract(off)
+    return a * __builtin_amdgcn_rcpf(b);
+}
 #endif
 
 // Categorical over softmax probabilities, restating torch/distributions/categorical.py:71
@@ -286,6 +320,7 @@ struct CatOut {
 
 template <int AOUT>
 __device__ __forceinline__ void categorical_head(const float (&o)[AOUT], int A, CatOut<AOUT>& out) {
+#pragma clang fp contract(off)
     float mx = o[0];
 #pragma unroll
     for (int a = 1; a < AOUT; ++a) if (a < A) mx = fmaxf(mx, o[a]);
@@ -321,6 +356,7 @@ struct GaussOut {
 template <int AOUT>
 __device__ __forceinline__ void gaussian_head(const float (&o)[AOUT], int A, float action_var,
                                               const float (&act)[AOUT], GaussOut<AOUT>& out) {
+#pragma clang fp contract(off)
     const float sigma = sqrtf(action_var);
     const float ls = logf(sigma);
     float M = 0.f, hld = 0.f;
@@ -371,15 +407,154 @@ struct Philox {
         out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
         ++c[3];  // next block of this (stream, index)
     }
+    // continue with block b (< 256) of this (stream, index): blocks are independent draws
+    __device__ void set_block(uint32_t b) { c[3] = (c[3] & 0xFFFFFF00u) | b; }
 };
 
 __device__ __forceinline__ float u01(uint32_t x) {  // (0, 1]
+#pragma clang fp contract(off)
     return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+#pragma clang fp contract(off)
     const float r = sqrtf(-2.0f * logf(u01(a)));
     const float th = 6.283185307179586f * u01(b);
     n0 = r * cosf(th);
     n1 = r * sinf(th);
+}
+
+// ------------------------------------------------------------------ policy head of act()
+// From the actor's pre-head outputs o[] of sample m: sample an action (SAMPLE) or read the given one,
+// and return its log-prob and the entropy (ActorCritic.act / evaluate, PPO.py:86-121).  Both
+// half-waves hold the same sample and compute the same values; the h == 0 lane stores the action.
+template <bool CONT, int AMAX, bool SAMPLE>
+__device__ __forceinline__ void policy_head_act(const float (&o)[AMAX], int A, float action_var,
+                                                uint64_t seed, uint64_t rng_offset, int64_t m,
+                                                bool valid, int h, void* __restrict__ actions_io,
+                                                float& logp, float& ent, int& action_out) {
+#pragma clang fp contract(off)
+    action_out = 0;
+    if constexpr (CONT) {
+        float act[AMAX];
+        float* ap = reinterpret_cast<float*>(actions_io);
+        if constexpr (SAMPLE) {
+            // MultivariateNormal.rsample: loc + scale_tril @ eps (multivariate_normal.py:250-253)
+            Philox rng(seed, rng_offset, (uint64_t)m);
+            const float sigma = sqrtf(action_var);
+#pragma unroll
+            for (int a = 0; a < AMAX; a += 4) {
+                uint32_t u[4];
+                rng.next(u);
+                float e[4];
+                box_muller(u[0], u[1], e[0], e[1]);
+                box_muller(u[2], u[3], e[2], e[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (a + j < AMAX) act[a + j] = tanh_head(o[a + j]) + sigma * e[j];
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) act[a] = (valid && a < A) ? ap[m * A + a] : 0.f;
+        }
+        GaussOut<AMAX> g;
+        gaussian_head<AMAX>(o, A, action_var, act, g);
+        logp = g.logp;
+        ent = g.ent;
+        if (SAMPLE && valid && h == 0) {
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) if (a < A) ap[m * A + a] = act[a];
+        }
+    } else {
+        CatOut<AMAX> cat;
+        categorical_head<AMAX>(o, A, cat);
+        int* ap = reinterpret_cast<int*>(actions_io);
+        int action;
+        if constexpr (SAMPLE) {
+            Philox rng(seed, rng_offset, (uint64_t)m);
+            uint32_t u[4];
+            rng.next(u);
+            const float uu = 1.0f - u01(u[0]);  // [0, 1)
+            float cum = 0.f;
+            action = A - 1;
+            bool done = false;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < A) {
+                    cum += cat.q[a];
+                    if (!done && uu < cum) { action = a; done = true; }
+                }
+            }
+            if (valid && h == 0) ap[m] = action;
+        } else {
+            action = valid ? ap[m] : 0;
+        }
+        logp = cat.L[0];
+#pragma unroll
+        for (int a = 1; a < AMAX; ++a) logp = (a == action) ? cat.L[a] : logp;
+        ent = cat.ent;
+        action_out = action;
+    }
+}
+
+// ------------------------------------------------------------------ synthetic env draws
+// Env e at step `step` draws from Philox(seed ^ C, step, e): block 0 -> reward (first normal) and
+// terminal (third word); block 1 + j -> observation entries 4j .. 4j+3 (standard normals).
+#define SYNTH_ENV_KEY 0x9E3779B97F4A7C15ull
+
+__device__ __forceinline__ void synth_env_reward_terminal(uint64_t seed, int64_t step, int64_t e,
+                                                          int reward_kind, float p_terminal,
+                                                          int64_t horizon, float& reward, bool& term) {
+    Philox rng(seed ^ SYNTH_ENV_KEY, (uint64_t)step, (uint64_t)e);
+    uint32_t u[4];
+    rng.next(u);
+    float n0, n1;
+    box_muller(u[0], u[1], n0, n1);
+    reward = reward_kind == 0 ? 1.0f : n0;
+    if (p_terminal < 0.f) term = (step % horizon) == horizon - 1;
+    else term = (1.0f - u01(u[2])) < p_terminal;
+}
+
+__device__ __forceinline__ void synth_env_state_block(uint64_t seed, int64_t step, int64_t e, int j,
+                                                      float (&v)[4]) {
+    Philox rng(seed ^ SYNTH_ENV_KEY, (uint64_t)step, (uint64_t)e);
+    rng.set_block(1 + j);
+    uint32_t u[4];
+    rng.next(u);
+    box_muller(u[0], u[1], v[0], v[1]);
+    box_muller(u[2], u[3], v[2], v[3]);
+}
+
+// ------------------------------------------------------------------ CartPole-v1 dynamics
+// One Euler step of the published cart-pole equations (tau = 0.02 s, force +-10 N) on the fp64
+// state (x, x_dot, theta, theta_dot); returns true when the pole fell or the cart left the track.
+__device__ __forceinline__ bool cartpole_advance(double (&s)[4], int action) {
+#pragma clang fp contract(off)
+    const double gravity = 9.8, masspole = 0.1, total_mass = 1.1, length = 0.5,
+                 polemass_length = 0.05, force_mag = 10.0, tau = 0.02;
+    const double theta_thr = 12.0 * 2.0 * 3.141592653589793 / 360.0, x_thr = 2.4;
+    double x = s[0], xd = s[1], th = s[2], thd = s[3];
+    const double force = action == 1 ? force_mag : -force_mag;
+    const double ct = cos(th), st = sin(th);
+    const double temp = (force + polemass_length * (thd * thd) * st) / total_mass;
+    const double thacc = (gravity * st - ct * temp) /
+                         (length * (4.0 / 3.0 - masspole * (ct * ct) / total_mass));
+    const double xacc = temp - polemass_length * thacc * ct / total_mass;
+    x = x + tau * xd;
+    xd = xd + tau * xacc;
+    th = th + tau * thd;
+    thd = thd + tau * thacc;
+    s[0] = x; s[1] = xd; s[2] = th; s[3] = thd;
+    return x < -x_thr || x > x_thr || th < -theta_thr || th > theta_thr;
+}
+
+// reset draw of env e for its episode number ep: four values U(-0.05, 0.05)
+#define CARTPOLE_RESET_KEY 0xC2B2AE3D27D4EB4Full
+__device__ __forceinline__ void cartpole_reset_draw(uint64_t seed, unsigned ep, int64_t e, double (&s)[4]) {
+    Philox rng(seed ^ CARTPOLE_RESET_KEY, (uint64_t)ep, (uint64_t)e);
+    uint32_t u[4];
+    rng.next(u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)   // 32 random bits -> [0, 1) exactly representable in fp64
+        s[k] = ((double)u[k] * (1.0 / 4294967296.0) - 0.5) * 0.1;
 }
