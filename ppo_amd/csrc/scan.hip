@@ -208,31 +208,51 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_flat_apply(const RT* __restri
 }
 
 // Time-major [n_steps, n_envs]: one thread per env walks its column backwards (exactly the
-// reference's serial order); loads and stores of a step are coalesced across envs.
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_rows_kernel(const float* __restrict__ rewards,
+// reference's serial order, so the result is bit-exact); loads and stores of a step are coalesced
+// across envs.  The recurrence itself is two dependent fp64 operations per step; what has to be
+// hidden is memory latency, so the rewards / terminals of ROWS_PF steps are fetched into registers
+// before the chain runs over them (ROWS_PF loads in flight per lane instead of one).  One wave per
+// workgroup, so that a few thousand envs already spread over many CUs.
+#define ROWS_BLOCK 64
+#define ROWS_PF 32
+__global__ __launch_bounds__(ROWS_BLOCK) void scan_rows_kernel(const float* __restrict__ rewards,
                                                                const uint8_t* __restrict__ terminals,
                                                                int64_t n_steps, int64_t n_envs,
                                                                double gamma,
                                                                float* __restrict__ returns,
                                                                Mom* __restrict__ block_mom) {
-    __shared__ Mom mom_lds[SCAN_BLOCK / 64];
-    const int64_t e = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    __shared__ Mom mom_lds[4];
+    const int64_t e = (int64_t)blockIdx.x * ROWS_BLOCK + threadIdx.x;
     Mom m;
     m.n = 0.0;
     m.mean = 0.0;
     m.m2 = 0.0;
     if (e < n_envs) {
         double d = 0.0, shift = 0.0, s1 = 0.0, s2 = 0.0;
-        for (int64_t t = n_steps - 1; t >= 0; --t) {
-            const int64_t i = t * n_envs + e;
-            if (terminals[i]) d = 0.0;
-            d = __dadd_rn((double)rewards[i], __dmul_rn(gamma, d));
-            const float o = (float)d;
-            returns[i] = o;
-            if (t == n_steps - 1) shift = (double)o;
-            const double y = (double)o - shift;
-            s1 += y;
-            s2 += y * y;
+        for (int64_t hi = n_steps; hi > 0; hi -= ROWS_PF) {   // steps hi-1 .. hi-ROWS_PF, backwards
+            float r[ROWS_PF];
+            uint8_t tm[ROWS_PF];
+#pragma unroll
+            for (int j = 0; j < ROWS_PF; ++j) {
+                const int64_t t = hi - 1 - j;
+                const int64_t i = (t >= 0 ? t : 0) * n_envs + e;
+                r[j] = rewards[i];
+                tm[j] = terminals[i];
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS_PF; ++j) {
+                const int64_t t = hi - 1 - j;
+                if (t >= 0) {
+                    if (tm[j]) d = 0.0;
+                    d = __dadd_rn((double)r[j], __dmul_rn(gamma, d));
+                    const float o = (float)d;
+                    returns[t * n_envs + e] = o;
+                    if (t == n_steps - 1) shift = (double)o;
+                    const double y = (double)o - shift;
+                    s1 += y;
+                    s2 += y * y;
+                }
+            }
         }
         m.n = (double)n_steps;
         m.mean = shift + s1 / m.n;
@@ -264,7 +284,9 @@ __global__ __launch_bounds__(256) void moments_finalize(const Mom* __restrict__ 
 // PPO.py:212 (elementwise) + PPO.py:221.  fp32 arithmetic exactly as the reference's tensors:
 // mean and std are fp32 scalars, 1e-7 is added to the fp32 std, the division is IEEE.
 // returns_norm may be the same buffer as returns (each thread reads an element before it writes
-// it), so neither of the two is declared __restrict__.
+// it), so neither of the two is declared __restrict__.  16-byte accesses when all four pointers
+// are 16-byte aligned (VEC), one element per thread otherwise.
+template <bool VEC>
 __global__ __launch_bounds__(256) void normalize_adv_kernel(const float* returns,
                                                             const float* __restrict__ old_values,
                                                             int64_t n,
@@ -276,10 +298,32 @@ __global__ __launch_bounds__(256) void normalize_adv_kernel(const float* returns
     const float stdv = (float)sqrt(moments[2] / fmax(cnt - 1.0, 1.0));
     const float denom = stdv + 1e-7f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float rn = (returns[i] - mean) / denom;
-        returns_norm[i] = rn;
-        adv[i] = rn - old_values[i];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += stride) {
+            const f32x4 r = reinterpret_cast<const f32x4*>(returns)[i];
+            const f32x4 v = reinterpret_cast<const f32x4*>(old_values)[i];
+            f32x4 rn, ad;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rn[j] = (r[j] - mean) / denom;
+                ad[j] = rn[j] - v[j];
+            }
+            reinterpret_cast<f32x4*>(returns_norm)[i] = rn;
+            reinterpret_cast<f32x4*>(adv)[i] = ad;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {
+            const float rn = (returns[i] - mean) / denom;
+            returns_norm[i] = rn;
+            adv[i] = rn - old_values[i];
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) {
+            const float rn = (returns[i] - mean) / denom;
+            returns_norm[i] = rn;
+            adv[i] = rn - old_values[i];
+        }
     }
 }
 
@@ -289,7 +333,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // workspace carve for the scan: [Aff nb][double nb][Mom nb]
 size_t ppo_scan_ws_bytes(int64_t n) {
     const size_t nb = (size_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK) + 1;
-    const size_t nb_rows = (size_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK) + 1;
+    const size_t nb_rows = (size_t)((n + ROWS_BLOCK - 1) / ROWS_BLOCK) + 1;   // >= one block per 64 envs
     const size_t m = nb > nb_rows ? nb : nb_rows;
     return align_up(m * sizeof(Aff), 256) + align_up(m * sizeof(double), 256) +
            align_up(m * sizeof(Mom), 256);
@@ -387,12 +431,9 @@ extern "C" int ppo_returns_scan_rows(const float* rewards_tn, const uint8_t* ter
         return PPO_E_BADARG;
     if (!workspace || workspace_bytes < ppo_scan_ws_bytes(n_steps * n_envs)) return PPO_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = (int)((n_envs + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    char* w = (char*)workspace;
-    w += align_up((size_t)(nb + 1) * sizeof(Aff), 256);
-    w += align_up((size_t)(nb + 1) * sizeof(double), 256);
-    Mom* mom = (Mom*)w;
-    scan_rows_kernel<<<nb, SCAN_BLOCK, 0, st>>>(rewards_tn, terminals_tn, n_steps, n_envs, gamma,
+    const int nb = (int)((n_envs + ROWS_BLOCK - 1) / ROWS_BLOCK);
+    Mom* mom = (Mom*)workspace;   // nb block moments; ppo_scan_ws_bytes() covers (nb + 1) * sizeof(Mom)
+    scan_rows_kernel<<<nb, ROWS_BLOCK, 0, st>>>(rewards_tn, terminals_tn, n_steps, n_envs, gamma,
                                                 returns_tn, mom);
     moments_finalize<<<1, 256, 0, st>>>(mom, nb, moments_out);
     return (int)hipGetLastError();
@@ -403,9 +444,15 @@ extern "C" int ppo_normalize_advantage(const float* returns, const float* old_va
                                        float* advantages, void* stream) {
     if (!returns || !old_values || !moments || !returns_norm || !advantages || n <= 0)
         return PPO_E_BADARG;
-    const int64_t want = (n + 255) / 256;
-    const int grid = (int)(want < 2048 ? want : 2048);
-    normalize_adv_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(returns, old_values, n, moments,
-                                                               returns_norm, advantages);
+    const bool vec = (((uintptr_t)returns | (uintptr_t)old_values | (uintptr_t)returns_norm |
+                       (uintptr_t)advantages) & 15) == 0;
+    const int64_t want = ((vec ? (n + 3) / 4 : n) + 255) / 256;
+    const int grid = (int)(want < 4096 ? want : 4096);
+    if (vec)
+        normalize_adv_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(returns, old_values, n, moments,
+                                                                         returns_norm, advantages);
+    else
+        normalize_adv_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(returns, old_values, n, moments,
+                                                                          returns_norm, advantages);
     return (int)hipGetLastError();
 }
