@@ -154,10 +154,12 @@ int ppo_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
 
 /* ---- single-env latency path -------------------------------------------------------------------
  * PPO.select_action as the reference's loop calls it (PPO.py:175-198, train.py:176): ONE state on
- * the host in, ONE action on the host out.  Copies host_state (state_dim floats; page-locked memory
- * makes the copy asynchronous) into state_row, runs ppo_act on that row (n = 1), copies the action
- * (int32, or action_dim floats) to host_action_out and waits for the stream.  state_row /
- * action_row / logprob_row / value_row are the rollout buffer's device rows for this step. */
+ * the host in, ONE action on the host out.  host_state (state_dim floats) and host_action_out (int32,
+ * or action_dim floats) must be PAGE-LOCKED host buffers (hipHostMalloc / torch pin_memory): the
+ * kernel reads the observation from host_state directly, files it in state_row, runs ppo_act's
+ * arithmetic on it (n = 1) and writes the action to action_row and to host_action_out; then the
+ * stream is waited for.  One launch, no copy commands.  state_row / action_row / logprob_row /
+ * value_row are the rollout buffer's device rows for this step. */
 int ppo_act_host(const float* params, int state_dim, int action_dim, int continuous, float action_var,
                  const float* host_state, float* state_row, uint64_t seed, uint64_t rng_offset,
                  void* action_row, float* logprob_row, float* value_row, void* host_action_out,

@@ -10,7 +10,12 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
                                                   void* __restrict__ actions_io,
                                                   float* __restrict__ logprobs,
                                                   float* __restrict__ values,
-                                                  float* __restrict__ entropy) {
+                                                  float* __restrict__ entropy,
+                                                  float* __restrict__ states_copy,
+                                                  void* __restrict__ actions_dup) {
+    // states_copy (optional): the observations are also written there (the rollout buffer's rows when
+    // `states` is a page-locked host buffer); actions_dup (optional): second destination of the
+    // sampled actions (a page-locked host buffer the caller reads after the stream has drained).
     // Even workgroups run the actor on four 32-sample tiles, odd ones the critic on the same
     // tiles: each stages only its own network into LDS and the two halves of a step run side by side.
     extern __shared__ __align__(16) float smem[];
@@ -28,6 +33,8 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
         float v[1];
         out_layer<1>(LC, 1, H2, h, v);
         if (valid && h == 0 && values) values[m] = v[0];
+        if (states_copy && valid && h == 0)
+            for (int k = 0; k < S; ++k) states_copy[m * S + k] = states[m * S + k];
         return;
     }
     const NetLds LA = carve_net_lds(smem, S, AMAX, false);
@@ -38,10 +45,18 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
     float o[AMAX];
     out_layer<AMAX>(LA, A, H2, h, o);
 
-    float logp, ent;
+    float logp, ent, act_c[AMAX];
     int action;
     policy_head_act<CONT, AMAX, SAMPLE>(o, A, action_var, seed, rng_offset, m, valid, h, actions_io, logp, ent,
-                                        action);
+                                        action, act_c);
+    if (SAMPLE && actions_dup && valid && h == 0) {
+        if constexpr (CONT) {
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) if (k < A) reinterpret_cast<float*>(actions_dup)[m * A + k] = act_c[k];
+        } else {
+            reinterpret_cast<int*>(actions_dup)[m] = action;
+        }
+    }
 
     if (valid && h == 0) {
         if (logprobs) logprobs[m] = logp;
@@ -53,7 +68,7 @@ template <bool SAMPLE>
 static int launch_act(const float* params, int S, int A, int continuous, float action_var,
                       const float* states, int64_t n, uint64_t seed, uint64_t rng_offset,
                       void* actions, float* logprobs, float* values, float* entropy,
-                      hipStream_t st) {
+                      hipStream_t st, float* states_copy = nullptr, void* actions_dup = nullptr) {
     if (!params || !states || !actions || n <= 0) return PPO_E_BADARG;
     if (S < 1 || S > PPO_MAX_STATE_DIM || A < 1 || A > PPO_MAX_ACTION_DIM) return PPO_E_UNSUPPORTED;
     const int amax = A <= 4 ? 4 : 8;
@@ -72,7 +87,8 @@ static int launch_act(const float* params, int S, int A, int continuous, float a
         }                                                                                       \
         act_kernel<C, AM, SAMPLE><<<grid, 256, lds, st>>>(params, S, A, action_var, states, n,  \
                                                           seed, rng_offset, actions, logprobs,  \
-                                                          values, entropy);                     \
+                                                          values, entropy, states_copy,         \
+                                                          actions_dup);                         \
     }
     if (continuous) {
         if (amax == 4) ACT_LAUNCH(true, 4) else ACT_LAUNCH(true, 8)
@@ -92,24 +108,20 @@ extern "C" int ppo_act(const float* params, int state_dim, int action_dim, int c
 }
 
 // Single-env latency path (select_action as train.py:176 calls it, one state per call): host state
-// in, host action out, one call.  The state is copied into its buffer row, the batched kernel acts
-// on that one row, the action is copied back and the stream is waited for; with page-locked host
-// buffers both copies are asynchronous and the only wait is the final one.
+// in, host action out, one call.  host_state and host_action_out are page-locked host buffers, which
+// the device addresses directly: the kernel reads the observation from the host buffer (and files it
+// in its buffer row), and writes the sampled action both to its buffer row and to the host buffer.
+// One launch and one wait per step; no copy commands.
 extern "C" int ppo_act_host(const float* params, int state_dim, int action_dim, int continuous,
                             float action_var, const float* host_state, float* state_row,
                             uint64_t seed, uint64_t rng_offset, void* action_row, float* logprob_row,
                             float* value_row, void* host_action_out, void* stream) {
     if (!host_state || !state_row || !host_action_out) return PPO_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemcpyAsync(state_row, host_state, (size_t)state_dim * sizeof(float),
-                                  hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    const int rc = launch_act<true>(params, state_dim, action_dim, continuous, action_var, state_row, 1,
-                                    seed, rng_offset, action_row, logprob_row, value_row, nullptr, st);
+    const int rc = launch_act<true>(params, state_dim, action_dim, continuous, action_var, host_state, 1,
+                                    seed, rng_offset, action_row, logprob_row, value_row, nullptr, st,
+                                    state_row, host_action_out);
     if (rc) return rc;
-    const size_t abytes = continuous ? (size_t)action_dim * sizeof(float) : sizeof(int);
-    e = hipMemcpyAsync(host_action_out, action_row, abytes, hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return (int)e;
     return (int)hipStreamSynchronize(st);
 }
 

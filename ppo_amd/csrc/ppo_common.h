@@ -428,15 +428,16 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 // From the actor's pre-head outputs o[] of sample m: sample an action (SAMPLE) or read the given one,
 // and return its log-prob and the entropy (ActorCritic.act / evaluate, PPO.py:86-121).  Both
 // half-waves hold the same sample and compute the same values; the h == 0 lane stores the action.
+// action_out (discrete) / act[] (continuous) return the action to the caller as well.
 template <bool CONT, int AMAX, bool SAMPLE>
 __device__ __forceinline__ void policy_head_act(const float (&o)[AMAX], int A, float action_var,
                                                 uint64_t seed, uint64_t rng_offset, int64_t m,
                                                 bool valid, int h, void* __restrict__ actions_io,
-                                                float& logp, float& ent, int& action_out) {
+                                                float& logp, float& ent, int& action_out,
+                                                float (&act)[AMAX]) {
 #pragma clang fp contract(off)
     action_out = 0;
     if constexpr (CONT) {
-        float act[AMAX];
         float* ap = reinterpret_cast<float*>(actions_io);
         if constexpr (SAMPLE) {
             // MultivariateNormal.rsample: loc + scale_tril @ eps (multivariate_normal.py:250-253)

@@ -135,11 +135,11 @@ __global__ __launch_bounds__(128) void rollout_kernel(const RolloutArgs a) {
             mlp_fwd_tile_x(LA, S, x, c, h, H1, H2);
             float o[AMAX];
             out_layer<AMAX>(LA, A, H2, h, o);
-            float logp, ent;
+            float logp, ent, act_c[AMAX];
             int action;
             void* arow = CONT ? (void*)((float*)a.actions + (size_t)t * N * A) : (void*)((int*)a.actions + (size_t)t * N);
             policy_head_act<CONT, AMAX, true>(o, A, a.action_var, a.act_seed, a.act_offset0 + t, m, valid, h,
-                                              arow, logp, ent, action);
+                                              arow, logp, ent, action, act_c);
             if (valid && h == 0) a.logp[row] = logp;
             if constexpr (ENV == ENV_CARTPOLE) {
                 if (env_lane) {

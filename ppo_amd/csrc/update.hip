@@ -1,8 +1,8 @@
 // K-epoch update: fused evaluate + clipped-surrogate loss + backward (one launch per epoch),
 // deterministic gradient reduction, two-learning-rate Adam.
 //
-// fwdbwd kernel.  256 workgroups (one per CU) of 8 waves; even workgroups train the actor, odd ones
-// the critic (the two MLPs share no parameters and, given the precomputed advantages, their loss
+// fwdbwd kernel.  Up to 256 workgroups (one per CU) of 8 waves; the first n_actor_wg train the actor,
+// the rest the critic (the two MLPs share no parameters and, given the precomputed advantages, their loss
 // terms are independent: PPO.py:221,240).  On gfx950 the fp32 MFMA runs on the fp32 VALU datapath
 // (tools/ubench/mfma_valu_overlap.hip: VALU work between MFMAs adds its full issue time at any
 // occupancy), so the kernel's time is (MFMA count x 64 cycles) + (every other instruction), and the
@@ -78,7 +78,8 @@ struct FwdBwdArgs {
     float* partial_actor;   // [n_actor_wg][stride_actor]
     float* partial_critic;  // [FB_GRID - n_actor_wg][stride_critic]
     int n_actor_wg;         // workgroups 0 .. n_actor_wg-1 train the actor, the rest the critic
-    int* ws_header;         // [0] <- n_actor_wg: the reduction kernels read the split from here
+    int n_critic_wg;        // (host side only: the grid is n_actor_wg + n_critic_wg workgroups)
+    int* ws_header;         // [0] <- n_actor_wg, [1] <- critic workgroups: read back by the reduction kernels
     int stride_actor, stride_critic;
 };
 
@@ -726,7 +727,10 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
 template <bool CONT, int AMAX, int L1>
 __global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs a) {
     extern __shared__ __align__(16) float smem[];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.ws_header[0] = a.n_actor_wg;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.ws_header[0] = a.n_actor_wg;
+        a.ws_header[1] = (int)gridDim.x - a.n_actor_wg;
+    }
     if ((int)blockIdx.x < a.n_actor_wg)
         run_role<CONT ? HEAD_GAUSSIAN : HEAD_CATEGORICAL, AMAX, L1>(a, smem);
     else
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restric
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
     const int P = n_actor + n_critic;
-    const int rows_actor = ws_header[0], rows_critic = FB_GRID - rows_actor;
+    const int rows_actor = ws_header[0], rows_critic = ws_header[1];
     double s = 0.0;
     if (i < P + 2) {
         const float* src;
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
     const int P = n_actor + n_critic;
-    const int rows_actor = ws_header[0], rows_critic = FB_GRID - rows_actor;
+    const int rows_actor = ws_header[0], rows_critic = ws_header[1];
     double s = 0.0;
     if (i < P + 2) {
         const float* src;
@@ -858,22 +862,29 @@ static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
 // The fwd/bwd kernel leaves the split in the workspace header for the reduction kernels.
 #define FB_MAX_ROLE_WGS (3 * FB_GRID / 4)
 #define FB_WS_HEADER 256
-static int actor_wgs(int A, int64_t n) {
+static void role_wgs(int A, int64_t n, int& n_actor, int& n_critic) {
     static const char* tune = getenv("PPO_ACTOR_WGS");   // tuning aid: fixed split for every shape
-    if (tune && atoi(tune) >= FB_GRID - FB_MAX_ROLE_WGS && atoi(tune) <= FB_MAX_ROLE_WGS) return atoi(tune);
-    const double r = 1.0 + (A > 2 ? 0.062 : 0.072) * A;
     const int64_t tiles = (n + TILE_M - 1) / TILE_M;
     int best = FB_GRID / 2;
-    double best_cost = 1e300;
-    for (int na = FB_GRID - FB_MAX_ROLE_WGS; na <= FB_MAX_ROLE_WGS; ++na) {
-        const int64_t ia = (tiles + FB_PAIRS * na - 1) / (FB_PAIRS * na);
-        const int64_t ic = (tiles + FB_PAIRS * (FB_GRID - na) - 1) / (FB_PAIRS * (FB_GRID - na));
-        const double ca = ia * r, cc = (double)ic;
-        // ties (small buffers): prefer the split closest to the continuous optimum
-        const double cost = (ca > cc ? ca : cc) * (1.0 + 1e-6 * fabs(na - FB_GRID * r / (1.0 + r)));
-        if (cost < best_cost) { best_cost = cost; best = na; }
+    if (tune && atoi(tune) >= FB_GRID - FB_MAX_ROLE_WGS && atoi(tune) <= FB_MAX_ROLE_WGS) {
+        best = atoi(tune);
+    } else {
+        const double r = 1.0 + (A > 2 ? 0.062 : 0.072) * A;
+        double best_cost = 1e300;
+        for (int na = FB_GRID - FB_MAX_ROLE_WGS; na <= FB_MAX_ROLE_WGS; ++na) {
+            const int64_t ia = (tiles + FB_PAIRS * na - 1) / (FB_PAIRS * na);
+            const int64_t ic = (tiles + FB_PAIRS * (FB_GRID - na) - 1) / (FB_PAIRS * (FB_GRID - na));
+            const double ca = ia * r, cc = (double)ic;
+            // ties (small buffers): prefer the split closest to the continuous optimum
+            const double cost = (ca > cc ? ca : cc) * (1.0 + 1e-6 * fabs(na - FB_GRID * r / (1.0 + r)));
+            if (cost < best_cost) { best_cost = cost; best = na; }
+        }
     }
-    return best;
+    // Small buffers: a workgroup without a tile would still stage the weights and write a full row
+    // of (zero) partial sums that the reduction then reads; launch only the workgroups that get one.
+    const int needed = (int)((tiles + FB_PAIRS - 1) / FB_PAIRS);
+    n_actor = best < needed ? best : needed;
+    n_critic = FB_GRID - best < needed ? FB_GRID - best : needed;
 }
 
 // [header | actor partials, FB_MAX_ROLE_WGS rows | critic partials, FB_MAX_ROLE_WGS rows]
@@ -916,7 +927,7 @@ static int launch_fwdbwd(const FwdBwdArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         configured = lds;
     }
-    fwdbwd_kernel<CONT, AMAX, L1><<<FB_GRID, FB_THREADS, lds, st>>>(a);
+    fwdbwd_kernel<CONT, AMAX, L1><<<a.n_actor_wg + a.n_critic_wg, FB_THREADS, lds, st>>>(a);
     return (int)hipGetLastError();
 }
 
@@ -962,7 +973,7 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
     a.stride_critic = stride_of(n_critic_params(state_dim));
     a.ws_header = (int*)workspace;
     a.partial_actor = (float*)((char*)workspace + FB_WS_HEADER);
-    a.n_actor_wg = actor_wgs(action_dim, n_local);
+    role_wgs(action_dim, n_local, a.n_actor_wg, a.n_critic_wg);
     a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
     hipStream_t st = (hipStream_t)stream;
     const int l1 = state_dim + 1 <= 16 ? 0 : (state_dim + 1 <= 32 ? 1 : 2);

@@ -167,6 +167,10 @@ class RolloutBuffer:
                 new[:self._cap] = old
             self._store[name] = new
         self._cap = cap
+        # base address and row size in bytes of every column: the single-step path computes row
+        # addresses arithmetically instead of slicing tensors
+        self._row_addr = {name: (t.data_ptr(), t.stride(0) * t.element_size() if t.dim() else 0)
+                          for name, t in self._store.items()}
 
     def rows(self, name, lo, hi):
         return self._store[name][lo:hi]
@@ -529,17 +533,22 @@ class PPO:
                          torch.empty(max(self.action_dim, 1), dtype=torch.float32).pin_memory())
             self._pin_np = (self._pin[0].numpy(), self._pin[1].numpy(),
                             self._pin[1].numpy().view(np.int32))
+            self._pin_ptr = (self._pin[0].data_ptr(), self._pin[1].data_ptr())
+            self._act_host = _lib.lib().ppo_act_host
         self._pin_np[0][:] = state
         b = self.buffer
         lo = b.claim_step(1)
         seed, off = self._next_rng()
         pol = self.policy_old
         cont = self.has_continuous_action_space
-        _lib.check(_lib.lib().ppo_act_host(
-            pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var32(),
-            self._pin[0].data_ptr(), b.rows("states", lo, lo + 1).data_ptr(), seed, off,
-            b.rows("actions", lo, lo + 1).data_ptr(), b.rows("logprobs", lo, lo + 1).data_ptr(),
-            b.rows("state_values", lo, lo + 1).data_ptr(), self._pin[1].data_ptr(), _lib.stream_ptr()))
+        ra = b._row_addr
+        (ps, ss), (pa, sa), (pl, sl), (pv, sv) = ra["states"], ra["actions"], ra["logprobs"], ra["state_values"]
+        rc = self._act_host(
+            pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var_host,
+            self._pin_ptr[0], ps + lo * ss, seed, off, pa + lo * sa, pl + lo * sl, pv + lo * sv,
+            self._pin_ptr[1], torch.cuda.current_stream().cuda_stream)
+        if rc:
+            _lib.check(rc)
         if cont:
             return self._pin_np[1][:self.action_dim].copy()
         return int(self._pin_np[2][0])
