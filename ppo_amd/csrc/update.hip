@@ -26,12 +26,13 @@
 // Nothing is accumulated with atomics: per-wave -> per-workgroup (fixed wave order through LDS) ->
 // ppo_grad_reduce (fixed workgroup order), so results are bit-reproducible run to run.
 #include "ppo_common.h"
+#include "update_common.h"
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #define FB_PAIRS 4
 #define FB_THREADS (FB_PAIRS * 2 * 64)
-#define FB_GRID 256                                    // one workgroup per CU, split between the roles
 // Per-pair hand-off space.  Rows are samples, columns hidden units, row stride W2_LD (= 68: 16-byte
 // aligned rows whose starts are 4 banks apart, so 16-byte accesses of 8 consecutive rows and 4-byte
 // accesses of 32 consecutive columns are both conflict-free).
@@ -58,137 +59,6 @@ extern "C" void ppo_debug_set_stamps(void* p) { g_stamp_buf = (unsigned long lon
 #define STAMP(i)
 #define STAMP_FLUSH(a, wave)
 #endif
-
-struct FwdBwdArgs {
-    unsigned long long* stamps;
-    const float* params;
-    int S, A;
-    float action_var;
-    const float* states;
-    const void* actions;
-    const float* old_logp;
-    const float* adv;
-    const float* ret;
-    int64_t n;
-    float inv_n, clip_lo, clip_hi;
-    float* out_logp;
-    float* out_val;
-    float* out_ent;
-    float* out_surr;
-    float* partial_actor;   // [n_actor_wg][stride_actor]
-    float* partial_critic;  // [FB_GRID - n_actor_wg][stride_critic]
-    int n_actor_wg;         // workgroups 0 .. n_actor_wg-1 train the actor, the rest the critic
-    int n_critic_wg;        // (host side only: the grid is n_actor_wg + n_critic_wg workgroups)
-    int* ws_header;         // [0] <- n_actor_wg, [1] <- critic workgroups: read back by the reduction kernels
-    int stride_actor, stride_critic;
-};
-
-__host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
-
-// ---------------------------------------------------------------------------- head + loss
-// Distribution head, PPO.py:233-240 loss terms and the gradient w.r.t. the head's inputs for one
-// sample per lane (both half-waves hold the same sample and compute the same values).
-// Per-sample inputs of the head, fetched at the top of the tile loop so that their global-memory
-// latency passes under the two MLP layers.
-template <int HEAD, int AOUT>
-struct HeadIn {
-    float ret, old_lp, adv;
-    int action;
-    float act[HEAD == HEAD_GAUSSIAN ? AOUT : 1];
-};
-
-template <int HEAD, int AOUT>
-__device__ __forceinline__ HeadIn<HEAD, AOUT> load_head_inputs(const FwdBwdArgs& a, int A, int64_t m,
-                                                               bool valid) {
-    HeadIn<HEAD, AOUT> in;
-    in.ret = 0.f; in.old_lp = 0.f; in.adv = 0.f; in.action = 0;
-    if constexpr (HEAD == HEAD_VALUE) {
-        in.ret = valid ? a.ret[m] : 0.f;
-    } else {
-        in.old_lp = valid ? a.old_logp[m] : 0.f;
-        in.adv = valid ? a.adv[m] : 0.f;
-        if constexpr (HEAD == HEAD_CATEGORICAL) {
-            in.action = valid ? reinterpret_cast<const int*>(a.actions)[m] : 0;
-        } else {
-            const float* ap = reinterpret_cast<const float*>(a.actions);
-#pragma unroll
-            for (int k = 0; k < AOUT; ++k) in.act[k] = (valid && k < A) ? ap[m * A + k] : 0.f;
-        }
-    }
-    return in;
-}
-
-template <int HEAD, int AOUT>
-__device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const float (&o)[AOUT],
-                                               const HeadIn<HEAD, AOUT>& in,
-                                               int64_t m, bool valid, bool writer,
-                                               float (&dout)[AOUT], double& loss_acc) {
-    if constexpr (HEAD == HEAD_VALUE) {
-        // 0.5 * MseLoss(state_values, rewards), PPO.py:240; d/dV of its mean = (V - R)/n
-        const float R = in.ret;
-        const float diff = o[0] - R;
-        dout[0] = valid ? diff * a.inv_n : 0.f;
-        if (valid && writer) {
-            loss_acc += (double)diff * (double)diff;
-            if (a.out_val) a.out_val[m] = o[0];
-        }
-    } else {
-        const float old_lp = in.old_lp;
-        const float adv = in.adv;
-        float logp, ent;
-        CatOut<AOUT> cat;
-        GaussOut<AOUT> gs;
-        int action = 0;
-        if constexpr (HEAD == HEAD_CATEGORICAL) {
-            action = in.action;
-            categorical_head<AOUT>(o, A, cat);
-            logp = cat.L[0];
-#pragma unroll
-            for (int k = 1; k < AOUT; ++k) logp = (k == action) ? cat.L[k] : logp;
-            ent = cat.ent;
-        } else {
-            gaussian_head<AOUT>(o, A, a.action_var, in.act, gs);
-            logp = gs.logp;
-            ent = gs.ent;
-        }
-        const float ratio = head_exp(logp - old_lp);
-        const float s1 = ratio * adv;
-        const float s2 = fminf(fmaxf(ratio, a.clip_lo), a.clip_hi) * adv;
-        const float surr = fminf(s1, s2);
-        // torch.min splits ties 1/2 + 1/2 and clamp passes gradient on the closed interval: inside
-        // the clip range the whole gradient flows through ratio; outside it only when the
-        // unclipped branch is the smaller one.
-        const bool inside = ratio >= a.clip_lo && ratio <= a.clip_hi;
-        const bool gate = inside || (adv >= 0.f ? ratio <= a.clip_hi : ratio >= a.clip_lo);
-        const float dlogp = (valid && gate) ? -(adv * ratio) * a.inv_n : 0.f;
-        const float dent = valid ? -0.01f * a.inv_n : 0.f;
-        if constexpr (HEAD == HEAD_CATEGORICAL) {
-            float pa = cat.pass[0], wq = 0.f;
-#pragma unroll
-            for (int k = 0; k < AOUT; ++k) {
-                pa = (k == action) ? cat.pass[k] : pa;
-                if (k < A) wq += (cat.L[k] + cat.pass[k]) * cat.q[k];
-            }
-#pragma unroll
-            for (int k = 0; k < AOUT; ++k) {
-                const float onehot = (k == action) ? 1.f : 0.f;
-                const float dz_logp = pa * (onehot - cat.q[k]);
-                const float dz_ent = -(cat.q[k] * ((cat.L[k] + cat.pass[k]) - wq));
-                dout[k] = k < A ? dlogp * dz_logp + dent * dz_ent : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < AOUT; ++k)
-                dout[k] = k < A ? dlogp * head_div(gs.zed[k], gs.sigma) * (1.0f - gs.mu[k] * gs.mu[k]) : 0.f;
-        }
-        if (valid && writer) {
-            loss_acc += (double)(-surr - 0.01f * ent);
-            if (a.out_logp) a.out_logp[m] = logp;
-            if (a.out_ent) a.out_ent[m] = ent;
-            if (a.out_surr) a.out_surr[m] = surr;
-        }
-    }
-}
 
 // Sum of per-lane partials over the 32 sample columns through `buf` (>= 32*CS_LD floats, private
 // to the calling wave): written as [register][lane], read back as 32 consecutive floats per hidden
@@ -862,9 +732,10 @@ static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
 // The fwd/bwd kernel leaves the split in the workspace header for the reduction kernels.
 #define FB_MAX_ROLE_WGS (3 * FB_GRID / 4)
 #define FB_WS_HEADER 256
-static void role_wgs(int A, int64_t n, int& n_actor, int& n_critic) {
+// tile: samples per tile; slots: tiles a workgroup works on at a time (wave pairs, or waves)
+static void role_wgs(int A, int64_t n, int tile, int slots, int& n_actor, int& n_critic) {
     static const char* tune = getenv("PPO_ACTOR_WGS");   // tuning aid: fixed split for every shape
-    const int64_t tiles = (n + TILE_M - 1) / TILE_M;
+    const int64_t tiles = (n + tile - 1) / tile;
     int best = FB_GRID / 2;
     if (tune && atoi(tune) >= FB_GRID - FB_MAX_ROLE_WGS && atoi(tune) <= FB_MAX_ROLE_WGS) {
         best = atoi(tune);
@@ -872,8 +743,8 @@ static void role_wgs(int A, int64_t n, int& n_actor, int& n_critic) {
         const double r = 1.0 + (A > 2 ? 0.062 : 0.072) * A;
         double best_cost = 1e300;
         for (int na = FB_GRID - FB_MAX_ROLE_WGS; na <= FB_MAX_ROLE_WGS; ++na) {
-            const int64_t ia = (tiles + FB_PAIRS * na - 1) / (FB_PAIRS * na);
-            const int64_t ic = (tiles + FB_PAIRS * (FB_GRID - na) - 1) / (FB_PAIRS * (FB_GRID - na));
+            const int64_t ia = (tiles + slots * na - 1) / (slots * na);
+            const int64_t ic = (tiles + slots * (FB_GRID - na) - 1) / (slots * (FB_GRID - na));
             const double ca = ia * r, cc = (double)ic;
             // ties (small buffers): prefer the split closest to the continuous optimum
             const double cost = (ca > cc ? ca : cc) * (1.0 + 1e-6 * fabs(na - FB_GRID * r / (1.0 + r)));
@@ -882,7 +753,7 @@ static void role_wgs(int A, int64_t n, int& n_actor, int& n_critic) {
     }
     // Small buffers: a workgroup without a tile would still stage the weights and write a full row
     // of (zero) partial sums that the reduction then reads; launch only the workgroups that get one.
-    const int needed = (int)((tiles + FB_PAIRS - 1) / FB_PAIRS);
+    const int needed = (int)((tiles + slots - 1) / slots);
     n_actor = best < needed ? best : needed;
     n_critic = FB_GRID - best < needed ? FB_GRID - best : needed;
 }
@@ -973,7 +844,18 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
     a.stride_critic = stride_of(n_critic_params(state_dim));
     a.ws_header = (int*)workspace;
     a.partial_actor = (float*)((char*)workspace + FB_WS_HEADER);
-    role_wgs(action_dim, n_local, a.n_actor_wg, a.n_critic_wg);
+    // Symmetric-wave kernel (update_sym.hip) where selected; the forward/backward-pair kernel below
+    // otherwise.  PPO_FWDBWD=pair / sym forces one of them (cross-checks, A/B timing).
+    static const char* mode = getenv("PPO_FWDBWD");
+    bool sym = fwdbwd_sym_default(state_dim, action_dim, n_local);
+    if (mode && !strcmp(mode, "pair")) sym = false;
+    if (mode && !strcmp(mode, "sym")) sym = fwdbwd_sym_supported(state_dim, action_dim);
+    if (sym) {
+        role_wgs(action_dim, n_local, 16, 8, a.n_actor_wg, a.n_critic_wg);
+        a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
+        return launch_fwdbwd_sym(a, continuous, (hipStream_t)stream);
+    }
+    role_wgs(action_dim, n_local, TILE_M, FB_PAIRS, a.n_actor_wg, a.n_critic_wg);
     a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
     hipStream_t st = (hipStream_t)stream;
     const int l1 = state_dim + 1 <= 16 ? 0 : (state_dim + 1 <= 32 ? 1 : 2);

@@ -128,3 +128,20 @@ def test_full_size_iteration_equals_its_per_step_form(eng):
         res.append((agent.policy.flat.clone(), agent.last_loss.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.isfinite(res[0][1]).all()
+
+
+def test_symmetric_wave_kernel_passes_the_same_parity_cases():
+    """The alternative fwd/bwd kernel (symmetric waves on 16-sample tiles, PPO_FWDBWD=sym; the
+    variable is read once per process) against the same restatement / golden cases, in a child
+    process: every shape class it supports (S <= 31), the golden first-epoch and K-epoch cases."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PPO_FWDBWD="sym")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"),
+                        "-k", "every_shape_class or first_epoch_golden or k_epochs_golden or full_size_gradient"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
