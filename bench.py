@@ -253,10 +253,13 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
     phase_ms = {name: a.elapsed_time(b) for name, a, b in pev}
 
-    traffic, traffic_source = None, None
+    traffic, traffic_source, phase_traffic = None, None, {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(args.config, {})
+            pmc = json.load(f)
+        rec = pmc.get(args.config, {})
+        if not (args.n_envs or args.k_epochs):
+            phase_traffic = pmc.get("hbm_phases_" + args.config, {})
         if rec and not (args.n_envs or args.k_epochs):   # measured for the default shape only
             traffic = rec.get("bytes_per_launch")
             traffic_source = f"{rec.get('source')} (rocprofv3 --pmc passes of this workload, not measured by this run)"
@@ -268,14 +271,17 @@ def main():
         flops_launch = flops_per_sample_epoch(S, A) * n
         achieved = flops_launch / (kern_ms * 1e-3) / 1e12
         hbm = []
-        for name, kernel, bps in (("scan", "scan_flat_reduce/carries/apply + moments_finalize" if flat else
-                                   "scan_rows_kernel + moments_finalize", SCAN_BYTES_PER_STEP),
-                                  ("normalize", "normalize_adv_kernel", NORMALIZE_BYTES_PER_STEP)):
+        for name, kernel, pmc_key, bps in (("scan", "scan_flat_reduce/carries/apply + moments_finalize" if flat else
+                                            "scan_rows_kernel + moments_finalize", "scan_rows_kernel",
+                                            SCAN_BYTES_PER_STEP),
+                                           ("normalize", "normalize_adv_kernel", "normalize_adv_kernel",
+                                            NORMALIZE_BYTES_PER_STEP)):
             if name in phase_ms:
                 gbs = bps * n / (phase_ms[name] * 1e-3) / 1e9
                 hbm.append({"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": phase_ms[name],
-                            "bytes_per_step": bps})
+                            "frac": gbs / PEAK_HBM_GBS,
+                            "traffic": phase_traffic.get(pmc_key, {}).get("bytes_per_launch"),
+                            "avg_launch_ms": phase_ms[name], "bytes_per_step": bps})
         out = {
             "metric": "env-steps/sec (act+return scan+K-epoch update)",
             "value": steps_total / dt, "unit": "env-steps/s", "n_gpus": world,
