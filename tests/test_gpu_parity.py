@@ -143,6 +143,57 @@ def test_scan_rows_vs_oracle(eng, N, T):
     assert rel_err(flat.cpu().numpy().reshape(N, T), want) < 1e-6
 
 
+def test_scan_properties_random_shapes(eng):
+    """Property test over random lengths, terminal densities and discounts (hypothesis): the flat
+    scan equals the serial fp64 recurrence after the fp32 rounding (carries cross blocks through
+    re-associated fp64 arithmetic: identical except for rare double-rounding ties), the column scan
+    of a [T, N] rollout is bit-exact, and the all-terminal / no-terminal extremes hold."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    _, _lib = eng
+    L = _lib.lib()
+
+    @settings(max_examples=40, deadline=None, derandomize=True,
+              suppress_health_check=list(HealthCheck))
+    @given(T=st.integers(1, 9000), p=st.sampled_from([0.0, 0.002, 0.05, 0.5, 1.0]),
+           gamma=st.sampled_from([0.9, 0.99, 0.999, 1.0]), seed=st.integers(0, 2 ** 31 - 1),
+           f64=st.booleans())
+    def flat(T, p, gamma, seed, f64):
+        rng = np.random.default_rng(seed)
+        r = rng.standard_normal(T).astype(np.float32)
+        term = rng.random(T) < p
+        want = O.returns_scan(r, term, gamma).astype(np.float32)
+        out, mom = scan_flat(_lib, r, term, gamma, f64=f64)
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert rel_err(got, want) < 1e-6 and (got != want).sum() <= max(1, T // 2000)
+        if p == 1.0:
+            assert np.array_equal(got, r)                      # every step resets: return == reward
+        assert mom.cpu().numpy()[0] == T
+
+    @settings(max_examples=25, deadline=None, derandomize=True,
+              suppress_health_check=list(HealthCheck))
+    @given(N=st.integers(1, 700), T=st.integers(1, 140), p=st.sampled_from([0.0, 0.02, 1.0]),
+           seed=st.integers(0, 2 ** 31 - 1))
+    def rows(N, T, p, seed):
+        rng = np.random.default_rng(seed)
+        r = rng.standard_normal((N, T)).astype(np.float32)
+        term = rng.random((N, T)) < p
+        want = O.returns_scan_rows(r, term, 0.99).astype(np.float32)
+        out = torch.empty((T, N), dtype=torch.float32, device="cuda")
+        mom = torch.zeros(3, dtype=torch.float64, device="cuda")
+        ws = torch.empty(L.ppo_workspace_bytes(4, 2, N * T), dtype=torch.uint8, device="cuda")
+        r_tn, t_tn = dev(r.T.copy()), dev(term.T.copy().astype(np.uint8))    # keep both alive over the launch
+        _lib.check(L.ppo_returns_scan_rows(r_tn.data_ptr(), t_tn.data_ptr(), T, N, 0.99, out.data_ptr(),
+                                           mom.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().T, want)
+        n, mean, _ = mom.cpu().numpy()
+        assert n == N * T and abs(mean - want.astype(np.float64).mean()) < 1e-9 * N * T
+
+    flat()
+    rows()
+
+
 # ------------------------------------------------------------------------------ evaluate / act
 def flat_params(P):
     return dev(O.flatten_params(P))

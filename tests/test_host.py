@@ -235,3 +235,19 @@ def test_c_abi_argument_errors_without_touching_the_gpu():
         assert len(L.ppo_hip_strerror(code)) > 5
     with pytest.raises(RuntimeError):
         _lib.check(E_UNSUPPORTED)
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/ppo_hip.h is the C-ABI contract: it must compile as C (no C++, no HIP, no torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "ppo_hip.h"\n'
+                   'int probe(void) { return ppo_hip_abi_version() + (int)sizeof(&ppo_returns_scan_flat_noalloc)'
+                   ' + PPO_SCAN_NOALLOC_MAX / PPO_SCAN_NOALLOC_MAX; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
