@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
         __syncthreads();
         mlp_fwd_tile(LC, states, S, m, valid, c, h, H1, H2);
         float v[1];
-        out_layer<1>(LC, 1, H2, h, v);
+        out_layer_act<1>(LC, 1, H2, h, v);
         if (valid && h == 0 && values) values[m] = v[0];
         if (states_copy && valid && h == 0)
             for (int k = 0; k < S; ++k) states_copy[m * S + k] = states[m * S + k];
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
 
     mlp_fwd_tile(LA, states, S, m, valid, c, h, H1, H2);
     float o[AMAX];
-    out_layer<AMAX>(LA, A, H2, h, o);
+    out_layer_act<AMAX>(LA, A, H2, h, o);
 
     float logp, ent, act_c[AMAX];
     int action;

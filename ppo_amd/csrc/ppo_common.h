@@ -281,6 +281,178 @@ __device__ __forceinline__ void out_layer(const NetLds& L, int A, const f32x16 (
     }
 }
 
+// The out layer of act(): the same sum taken as four partial sums P_g, one per unit class
+// g = (unit bit 2) + 2 * (unit bit 0), each a chain of fmaf over the class's units in ascending order,
+// then o = (P_0 + P_1) + (P_2 + P_3) + b3.  A lane of the 32-sample tile holds two classes (g = h and
+// h + 2) and a lane of the 16-sample tile below holds one, so both tile shapes produce this sum bit
+// for bit (two independent chains here instead of one, too).
+template <int AOUT>
+__device__ __forceinline__ void out_layer_act(const NetLds& L, int A, const f32x16 (&H2)[2], int h,
+                                              float (&o)[AOUT]) {
+#pragma unroll
+    for (int a = 0; a < AOUT; ++a) {
+        float pa = 0.f, pb = 0.f;
+        if (a < A) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(&L.w3[a * HID + 32 * t + 8 * q + 4 * h]);
+                    pa = fmaf(w.x, H2[t][4 * q + 0], pa);
+                    pb = fmaf(w.y, H2[t][4 * q + 1], pb);
+                    pa = fmaf(w.z, H2[t][4 * q + 2], pa);
+                    pb = fmaf(w.w, H2[t][4 * q + 3], pb);
+                }
+            }
+            pa += other_half(pa);
+            pb += other_half(pb);
+            pa = (pa + pb) + L.b3[a];
+        }
+        o[a] = pa;
+    }
+}
+
+// ------------------------------------------------------------------ forward on a 16-sample tile
+// The same forward pass on v_mfma_f32_16x16x4_f32: a wave owns 16 samples, lane l holds sample
+// c = l & 15, and g = l >> 4 selects the quarter of the hidden units its registers carry.  Used where
+// a step's latency matters more than throughput (half the matrix and tanh work per wave and step).
+// Both fp32 MFMA shapes add their k-slices one after the other, lower lane group first, each with
+// one rounding (fmaf); the 32-sample tile's layer 2 therefore adds the units in the order
+// 0,4,1,5 | 2,6,3,7 | 8,12,9,13 | ...  Here lane group g carries the units
+//     u16(g, mb, r) = 16 mb + 8 (r >> 1) + 4 (g & 1) + 2 (r & 1) + (g >> 1)      (mb, r = 0..3),
+// which makes register 4 mb + r of an activation directly the B operand of k-step 4 mb + r in that
+// very order, and makes a lane's units one class of out_layer_act: every output bit equals the
+// 32-sample tile's.
+__device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__host__ __device__ inline int u16(int g, int mb, int r) {
+    return 16 * mb + 8 * (r >> 1) + 4 * (g & 1) + 2 * (r & 1) + (g >> 1);
+}
+
+// LDS image of one MLP for the 16-sample tile (floats):
+// w1 : [KS][4][64]     k-step s, output block mb, lane (c, g): W1s[u16(c >> 2, mb, c & 3)][k = 4 s + g]
+//                      (k == S: the bias, k > S: 0), x TANH_PRESCALE
+// w2 : [4][4][64][4]   output block mb, k-step group i4, lane, e: W2s[u16(c >> 2, mb, c & 3)][u16(g, i4, e)]
+// b2 : [4][4][4]       [mb][g][r] = b2s[u16(g, mb, r)]
+// w3 : [AOUT][4][4][4] [a][mb][g][r] = W3[a][u16(g, mb, r)] (rows >= A zero);  b3: [AOUT]
+struct Net16 {
+    float* w1;
+    float* w2;
+    float* b2;
+    float* w3;
+    float* b3;
+};
+
+__host__ __device__ inline int ks16_of(int S) { return (S + 4) / 4; }  // ceil((S+1)/4) k-steps
+
+__host__ __device__ inline int net16_lds_floats(int S, int aout) {
+    return ks16_of(S) * 256 + 4096 + 64 + aout * 64 + ((aout + 3) & ~3);
+}
+
+__device__ inline Net16 carve_net16(float* base, int S, int aout) {
+    Net16 L;
+    L.w1 = base;
+    L.w2 = L.w1 + ks16_of(S) * 256;
+    L.b2 = L.w2 + 4096;
+    L.w3 = L.b2 + 64;
+    L.b3 = L.w3 + aout * 64;
+    return L;
+}
+
+// Block-wide fill; caller synchronises afterwards.
+__device__ inline void fill_net16(const Net16& L, const float* __restrict__ params, const NetLayout& P,
+                                  int S, int A, int aout) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < ks16_of(S) * 256; i += nt) {
+        const int l = i & 63, mb = (i >> 6) & 3, s = i >> 8;
+        const int uo = u16((l & 15) >> 2, mb, l & 3), k = 4 * s + (l >> 4);
+        float v = 0.f;
+        if (k < S) v = params[P.w1 + uo * S + k];
+        else if (k == S) v = params[P.b1 + uo];
+        L.w1[i] = v * TANH_PRESCALE;
+    }
+    for (int i = tid; i < 4096; i += nt) {
+        const int e = i & 3, l = (i >> 2) & 63, i4 = (i >> 8) & 3, mb = i >> 10;
+        const int uo = u16((l & 15) >> 2, mb, l & 3), k = u16(l >> 4, i4, e);
+        L.w2[i] = params[P.w2 + uo * HID + k] * TANH_PRESCALE;
+    }
+    for (int i = tid; i < 64; i += nt)
+        L.b2[i] = params[P.b2 + u16((i >> 2) & 3, i >> 4, i & 3)] * TANH_PRESCALE;
+    for (int i = tid; i < aout * 64; i += nt) {
+        const int a = i >> 6;
+        L.w3[i] = a < A ? params[P.w3 + a * HID + u16((i >> 2) & 3, (i >> 4) & 3, i & 3)] : 0.f;
+    }
+    for (int i = tid; i < aout; i += nt) L.b3[i] = i < A ? params[P.b3 + i] : 0.f;
+}
+
+// The value lane ^ 16 holds (v_permlane16_swap: a register move between neighbouring 16-lane rows).
+__device__ __forceinline__ float other_row(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);  // r[0]: even rows' values, r[1]: odd rows'
+}
+
+// Forward of one 16-sample tile up to the pre-head outputs o[]; x(k) as in mlp_fwd_tile_x.
+template <int AOUT, class X>
+__device__ __forceinline__ void mlp_fwd_out16(const Net16& L, int S, int A, const X& x, int lane,
+                                              float (&o)[AOUT]) {
+    const int g = lane >> 4;
+    f32x4 z[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int ks = ks16_of(S);
+    for (int s = 0; s < ks; ++s) {
+        const int k = 4 * s + g;
+        float b = (k == S) ? 1.0f : 0.0f;   // ones column carries the bias
+        if (k < S) b = x(k);
+        const float* w = L.w1 + s * 256 + lane;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) z[mb] = mfma16x4(w[64 * mb], b, z[mb]);
+    }
+    f32x4 H1[4], y[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H1[mb][r] = tanh_prescaled(z[mb][r]);
+        y[mb] = *reinterpret_cast<const f32x4*>(L.b2 + 16 * mb + 4 * g);
+    }
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            a4[mb] = *reinterpret_cast<const f32x4*>(L.w2 + ((mb * 4 + i4) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) y[mb] = mfma16x4(a4[mb][e], H1[i4][e], y[mb]);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[mb][r] = tanh_prescaled(y[mb][r]);
+    }
+#pragma unroll
+    for (int a = 0; a < AOUT; ++a) {
+        float p = 0.f;
+        if (a < A) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(L.w3 + ((a * 4 + mb) * 4 + g) * 4);
+                p = fmaf(w.x, y[mb][0], p);
+                p = fmaf(w.y, y[mb][1], p);
+                p = fmaf(w.z, y[mb][2], p);
+                p = fmaf(w.w, y[mb][3], p);
+            }
+            p += other_row(p);     // P_g + P_(g^1): P_0 + P_1 on rows 0-1, P_2 + P_3 on rows 2-3
+            p += other_half(p);
+            p += L.b3[a];
+        }
+        o[a] = p;
+    }
+}
+
 // ------------------------------------------------------------------ heads
 // The head functions below switch floating-point contraction off: every multiply and add is
 // rounded as written, so the same (state, action) gives bit-identical log-probs in every kernel
@@ -503,27 +675,40 @@ __device__ __forceinline__ void policy_head_act(const float (&o)[AMAX], int A, f
 // terminal (third word); block 1 + j -> observation entries 4j .. 4j+3 (standard normals).
 #define SYNTH_ENV_KEY 0x9E3779B97F4A7C15ull
 
-__device__ __forceinline__ void synth_env_reward_terminal(uint64_t seed, int64_t step, int64_t e,
-                                                          int reward_kind, float p_terminal,
-                                                          int64_t horizon, float& reward, bool& term) {
+// Block b of env e at `step`: its four normals and its third word.  One instruction stream for
+// every block, so lanes that draw different blocks of one env run side by side.
+__device__ __forceinline__ void synth_env_block(uint64_t seed, int64_t step, int64_t e, int b,
+                                                float (&v)[4], uint32_t& word2) {
     Philox rng(seed ^ SYNTH_ENV_KEY, (uint64_t)step, (uint64_t)e);
-    uint32_t u[4];
-    rng.next(u);
-    float n0, n1;
-    box_muller(u[0], u[1], n0, n1);
-    reward = reward_kind == 0 ? 1.0f : n0;
-    if (p_terminal < 0.f) term = (step % horizon) == horizon - 1;
-    else term = (1.0f - u01(u[2])) < p_terminal;
-}
-
-__device__ __forceinline__ void synth_env_state_block(uint64_t seed, int64_t step, int64_t e, int j,
-                                                      float (&v)[4]) {
-    Philox rng(seed ^ SYNTH_ENV_KEY, (uint64_t)step, (uint64_t)e);
-    rng.set_block(1 + j);
+    rng.set_block((uint32_t)b);
     uint32_t u[4];
     rng.next(u);
     box_muller(u[0], u[1], v[0], v[1]);
     box_muller(u[2], u[3], v[2], v[3]);
+    word2 = u[2];
+}
+
+__device__ __forceinline__ void synth_reward_terminal_of(const float (&v)[4], uint32_t word2, int64_t step,
+                                                         int reward_kind, float p_terminal,
+                                                         int64_t horizon, float& reward, bool& term) {
+    reward = reward_kind == 0 ? 1.0f : v[0];
+    if (p_terminal < 0.f) term = (step % horizon) == horizon - 1;
+    else term = (1.0f - u01(word2)) < p_terminal;
+}
+
+__device__ __forceinline__ void synth_env_reward_terminal(uint64_t seed, int64_t step, int64_t e,
+                                                          int reward_kind, float p_terminal,
+                                                          int64_t horizon, float& reward, bool& term) {
+    float v[4];
+    uint32_t w2;
+    synth_env_block(seed, step, e, 0, v, w2);
+    synth_reward_terminal_of(v, w2, step, reward_kind, p_terminal, horizon, reward, term);
+}
+
+__device__ __forceinline__ void synth_env_state_block(uint64_t seed, int64_t step, int64_t e, int j,
+                                                      float (&v)[4]) {
+    uint32_t w2;
+    synth_env_block(seed, step, e, 1 + j, v, w2);
 }
 
 // ------------------------------------------------------------------ CartPole-v1 dynamics

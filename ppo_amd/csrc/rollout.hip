@@ -1,16 +1,20 @@
 // Whole lockstep rollouts in ONE launch: the loop of train.py:173-181 (select_action, env.step,
 // reward / terminal appends) for n_envs envs and n_steps steps.
 //
-// A workgroup owns a tile of 32 envs for all steps: wave 0 runs the actor (forward, head, sampling,
-// log-prob), wave 1 the critic; both MLP images are staged into LDS once.  The envs live inside the
-// kernel: the synthetic env's draws depend on (seed, step, env) only, so the critic wave produces the
-// next step's observations while the actor wave samples; the CartPole env integrates in the actor
+// A workgroup owns a tile of TM envs for all steps: wave 0 runs the actor (forward, head, sampling,
+// log-prob), wave 1 the critic, wave 2 (synthetic env only) the env; both MLP images are staged into
+// LDS once.  TM = 16 (the 16x16x4 MFMA
+// tile: half the matrix and tanh work in each step's dependent chain, twice the waves) by default,
+// TM = 32 on request; the two produce the same bits.  The envs live inside the
+// kernel: the synthetic env's draws depend on (seed, step, env) only, so the env wave produces the
+// next step's observations while the other two work on this one; the CartPole env integrates in the actor
 // wave's lanes, state in registers, right after the action is drawn.  Observations pass between the
 // waves through a double-buffered LDS tile (one workgroup barrier per step) and are written to the
 // time-major rollout buffer as they are produced.  Every arithmetic piece (MLP tile, heads, Philox
 // streams, env dynamics) is the device function the per-step kernels use, so the buffers written are
 // bit-identical to those of n_steps rounds of ppo_synth_env_step / ppo_cartpole_step + ppo_act.
 #include "ppo_common.h"
+#include <stdlib.h>
 
 #define ENV_SYNTH 0
 #define ENV_CARTPOLE 1
@@ -45,26 +49,56 @@ struct RolloutArgs {
 
 __host__ __device__ inline int stage_ld(int S) { return S | 1; }  // odd row stride: conflict-free column walks
 
-template <int ENV, bool CONT, int AMAX>
-__global__ __launch_bounds__(128) void rollout_kernel(const RolloutArgs a) {
+// One MLP's LDS image and forward for either tile shape.
+template <int TM> struct TileNet;
+template <> struct TileNet<32> {
+    NetLds L;
+    static __host__ __device__ int floats(int S, int aout) { return (net_lds_floats(S, aout, false) + 3) & ~3; }
+    __device__ void stage(float* base, const float* params, const NetLayout& P, int S, int A, int aout) {
+        L = carve_net_lds(base, S, aout, false);
+        fill_net_lds(L, params, P, S, A, aout, false);
+    }
+    template <int AOUT, class X>
+    __device__ __forceinline__ void forward(int S, int A, const X& x, int lane, float (&o)[AOUT]) const {
+        f32x16 H1[2], H2[2];
+        mlp_fwd_tile_x(L, S, x, lane & 31, lane >> 5, H1, H2);
+        out_layer_act<AOUT>(L, A, H2, lane >> 5, o);
+    }
+};
+template <> struct TileNet<16> {
+    Net16 L;
+    static __host__ __device__ int floats(int S, int aout) { return (net16_lds_floats(S, aout) + 3) & ~3; }
+    __device__ void stage(float* base, const float* params, const NetLayout& P, int S, int A, int aout) {
+        L = carve_net16(base, S, aout);
+        fill_net16(L, params, P, S, A, aout);
+    }
+    template <int AOUT, class X>
+    __device__ __forceinline__ void forward(int S, int A, const X& x, int lane, float (&o)[AOUT]) const {
+        mlp_fwd_out16<AOUT>(L, S, A, x, lane, o);
+    }
+};
+
+template <int ENV, bool CONT, int AMAX, int TM>
+__global__ __launch_bounds__(ENV == ENV_SYNTH ? 192 : 128) void rollout_kernel(const RolloutArgs a) {
     extern __shared__ __align__(16) float smem[];
     const int S = a.S, A = a.A;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int64_t m = (int64_t)blockIdx.x * TILE_M + c;   // this lane's env
+    // c: this lane's env in the tile; h: which of the 64 / TM lanes that hold the same env it is
+    constexpr int COPIES = 64 / TM;
+    const int lane = threadIdx.x & 63, h = lane / TM, c = lane % TM;
+    const int64_t m = (int64_t)blockIdx.x * TM + c;   // this lane's env
     const bool valid = m < a.n_envs;
     const int64_t N = a.n_envs;
 
     const NetLayout PA = net_layout(0, S, A);
     const NetLayout PC = net_layout(PA.n, S, 1);
-    const int actor_floats = (net_lds_floats(S, AMAX, false) + 3) & ~3;
-    const int critic_floats = (net_lds_floats(S, 1, false) + 3) & ~3;
-    const NetLds LA = carve_net_lds(smem, S, AMAX, false);
-    const NetLds LC = carve_net_lds(smem + actor_floats, S, 1, false);
+    const int actor_floats = TileNet<TM>::floats(S, AMAX);
+    const int critic_floats = TileNet<TM>::floats(S, 1);
+    TileNet<TM> NA, NC;
     const int SLD = stage_ld(S);
-    float* const stage = smem + actor_floats + critic_floats;      // [2][32][SLD]
-    fill_net_lds(LA, a.params, PA, S, A, AMAX, false);
-    fill_net_lds(LC, a.params, PC, S, 1, 1, false);
+    float* const stage = smem + actor_floats + critic_floats;      // [2][TM][SLD]
+    NA.stage(smem, a.params, PA, S, A, AMAX);
+    NC.stage(smem + actor_floats, a.params, PC, S, 1, 1);
 
     // ---- observation of step 0 -> stage[0] (+ the buffer's row 0)
     double cp[4] = {0.0, 0.0, 0.0, 0.0};
@@ -88,53 +122,54 @@ __global__ __launch_bounds__(128) void rollout_kernel(const RolloutArgs a) {
             if (a.fin_cnt) cp_fin_cnt = a.fin_cnt[m];
         }
     }
-    // synthetic env: draws of step t for this lane's env.  The observation blocks are split between
-    // the two half-waves (block j by half j & 1); reward / terminal go to the half with fewer blocks.
-    const int reward_half = ((S + 3) >> 2) & 1;
+    // synthetic env: draws of step t for this lane's env, by a wave of its own (the draws depend on
+    // (seed, step, env) only, so step t + 1 is drawn while the other two waves work on step t).  Block 0
+    // (reward, terminal) and the observation blocks 1.. are dealt round-robin to the lanes that hold
+    // the env.
     auto synth_generate = [&](int64_t t) {
         if (!valid) return;
         const int64_t row = t * N + m;
-        if (h == reward_half) {
-            float reward;
-            bool term;
-            synth_env_reward_terminal(a.env_seed, a.step0 + t, m, a.reward_kind, a.p_terminal, a.horizon,
-                                      reward, term);
-            a.rewards[row] = reward;
-            a.terminals[row] = term ? 1 : 0;
-        }
-        float* const srow = stage + ((t & 1) * TILE_M + c) * SLD;
-        for (int j = h; 4 * j < S; j += 2) {
+        float* const srow = stage + ((t & 1) * TM + c) * SLD;
+        const int nblk = 1 + ((S + 3) >> 2);
+        for (int b = h; b < nblk; b += COPIES) {
             float v[4];
-            synth_env_state_block(a.env_seed, a.step0 + t, m, j, v);
-            for (int i = 0; i < 4 && 4 * j + i < S; ++i) {
-                srow[4 * j + i] = v[i];
-                a.states[row * S + 4 * j + i] = v[i];
+            uint32_t w2;
+            synth_env_block(a.env_seed, a.step0 + t, m, b, v, w2);
+            if (b == 0) {
+                float reward;
+                bool term;
+                synth_reward_terminal_of(v, w2, a.step0 + t, a.reward_kind, a.p_terminal, a.horizon, reward, term);
+                a.rewards[row] = reward;
+                a.terminals[row] = term ? 1 : 0;
+            } else {
+                const int j = b - 1;
+                for (int i = 0; i < 4 && 4 * j + i < S; ++i) {
+                    srow[4 * j + i] = v[i];
+                    a.states[row * S + 4 * j + i] = v[i];
+                }
             }
         }
     };
     if constexpr (ENV == ENV_SYNTH) {
-        if (wave == 1) synth_generate(0);
+        if (wave == 2) synth_generate(0);
     }
 
     for (int64_t t = 0; t < a.n_steps; ++t) {
         __syncthreads();   // stage[t & 1] holds the observations of step t (and, first time, the images)
         const int64_t row = t * N + m;
-        const RowFromLds x{stage + ((t & 1) * TILE_M + c) * SLD, valid};
-        f32x16 H1[2], H2[2];
-        if (wave == 1) {
-            // ---------------- critic: value of the observation; synthetic env: next step's draws
-            mlp_fwd_tile_x(LC, S, x, c, h, H1, H2);
+        const RowFromLds x{stage + ((t & 1) * TM + c) * SLD, valid};
+        if (wave == 2) {
+            // ---------------- synthetic env: next step's draws
+            if (t + 1 < a.n_steps) synth_generate(t + 1);
+        } else if (wave == 1) {
+            // ---------------- critic: value of the observation
             float v[1];
-            out_layer<1>(LC, 1, H2, h, v);
+            NC.template forward<1>(S, 1, x, lane, v);
             if (valid && h == 0) a.values[row] = v[0];
-            if constexpr (ENV == ENV_SYNTH) {
-                if (t + 1 < a.n_steps) synth_generate(t + 1);
-            }
         } else {
             // ---------------- actor: sample the action, then (CartPole) step the env with it
-            mlp_fwd_tile_x(LA, S, x, c, h, H1, H2);
             float o[AMAX];
-            out_layer<AMAX>(LA, A, H2, h, o);
+            NA.template forward<AMAX>(S, A, x, lane, o);
             float logp, ent, act_c[AMAX];
             int action;
             void* arow = CONT ? (void*)((float*)a.actions + (size_t)t * N * A) : (void*)((int*)a.actions + (size_t)t * N);
@@ -158,7 +193,7 @@ __global__ __launch_bounds__(128) void rollout_kernel(const RolloutArgs a) {
                         cp_steps = steps;
                     }
                     // observation the next select_action sees: next row, or the carry after the last step
-                    float* const srow = stage + (((t + 1) & 1) * TILE_M + c) * SLD;
+                    float* const srow = stage + (((t + 1) & 1) * TM + c) * SLD;
                     float* const grow = t + 1 < a.n_steps ? a.states + (row + N) * 4 : a.obs_carry + m * 4;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -182,27 +217,39 @@ __global__ __launch_bounds__(128) void rollout_kernel(const RolloutArgs a) {
     }
 }
 
-static size_t rollout_lds_bytes(int S, int amax) {
-    const int actor_floats = (net_lds_floats(S, amax, false) + 3) & ~3;
-    const int critic_floats = (net_lds_floats(S, 1, false) + 3) & ~3;
-    return (size_t)(actor_floats + critic_floats + 2 * TILE_M * stage_ld(S)) * sizeof(float);
-}
-
-template <int ENV, bool CONT, int AMAX>
-static int launch_rollout(const RolloutArgs& a, hipStream_t st) {
-    const size_t lds = rollout_lds_bytes(a.S, AMAX);
+template <int ENV, bool CONT, int AMAX, int TM>
+static int launch_rollout_tm(const RolloutArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(TileNet<TM>::floats(a.S, AMAX) + TileNet<TM>::floats(a.S, 1) +
+                                2 * TM * stage_ld(a.S)) * sizeof(float);
     if (lds > 160 * 1024) return PPO_E_UNSUPPORTED;
     static size_t configured = 0;   // per process: one process drives one device
     if (lds > configured) {
-        const hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<ENV, CONT, AMAX>,
+        const hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<ENV, CONT, AMAX, TM>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = lds;
     }
-    const int64_t tiles = (a.n_envs + TILE_M - 1) / TILE_M;
+    const int64_t tiles = (a.n_envs + TM - 1) / TM;
     if (tiles > 0x7fffffff) return PPO_E_BADARG;
-    rollout_kernel<ENV, CONT, AMAX><<<(int)tiles, 128, lds, st>>>(a);
+    rollout_kernel<ENV, CONT, AMAX, TM><<<(int)tiles, ENV == ENV_SYNTH ? 192 : 128, lds, st>>>(a);
     return (int)hipGetLastError();
+}
+
+// 16-env tiles by default: measured faster than 32-env tiles both where the step chain is latency-bound
+// (4096 envs: 0.38 against 0.56 ms for 128 steps) and where the chip is full (65536 envs: 5.1 against
+// 5.4 ms).  PPO_ROLLOUT_TILE=32 selects the other shape (same bits).
+static int rollout_tile(int64_t) {
+    static const int forced = [] {
+        const char* e = getenv("PPO_ROLLOUT_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    return forced == 32 ? 32 : 16;
+}
+
+template <int ENV, bool CONT, int AMAX>
+static int launch_rollout(const RolloutArgs& a, hipStream_t st) {
+    if (rollout_tile(a.n_envs) == 16) return launch_rollout_tm<ENV, CONT, AMAX, 16>(a, st);
+    return launch_rollout_tm<ENV, CONT, AMAX, 32>(a, st);
 }
 
 extern "C" int ppo_synth_rollout(const float* params, int state_dim, int action_dim, int continuous,

@@ -500,11 +500,14 @@ def test_fused_reduce_adam_equals_two_launch(eng, name):
     assert agent.optimizer.step_count == 4
 
 
-@pytest.mark.parametrize("cont", [False, True])
-def test_synthetic_rollout_equals_per_step_calls(eng, cont):
-    """ppo_synth_rollout enqueues exactly the launches of the per-step API."""
+@pytest.mark.parametrize("cont,S,A,N,T", [(False, 4, 2, 333, 7), (True, 6, 3, 200, 5),
+                                          (True, 24, 6, 100, 3), (False, 63, 5, 50, 3),
+                                          (False, 17, 8, 16, 2), (True, 1, 1, 1, 4)])
+def test_synthetic_rollout_equals_per_step_calls(eng, cont, S, A, N, T):
+    """The one-launch rollout kernel (16-env tiles on the 16x16x4 MFMA, env in a wave of its own)
+    writes exactly the buffers of the per-step API (32-sample tiles on the 32x32x2 MFMA), bit for
+    bit, and the update that follows lands on the same parameters."""
     ppo, _lib = eng
-    S, A, N, T = (6, 3, 200, 5) if cont else (4, 2, 333, 7)
     cols = ("states", "actions", "logprobs", "state_values", "rewards", "is_terminals")
     got = []
     for fused in (True, False):
