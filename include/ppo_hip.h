@@ -154,16 +154,21 @@ int ppo_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
 
 /* ---- single-env latency path -------------------------------------------------------------------
  * PPO.select_action as the reference's loop calls it (PPO.py:175-198, train.py:176): ONE state on
- * the host in, ONE action on the host out.  host_state (state_dim floats) and host_action_out (int32,
- * or action_dim floats) must be PAGE-LOCKED host buffers (hipHostMalloc / torch pin_memory): the
- * kernel reads the observation from host_state directly, files it in state_row, runs ppo_act's
- * arithmetic on it (n = 1) and writes the action to action_row and to host_action_out; then the
- * stream is waited for.  One launch, no copy commands.  state_row / action_row / logprob_row /
- * value_row are the rollout buffer's device rows for this step. */
+ * the host in, ONE action on the host out.  host_state: state_dim floats of ordinary host memory
+ * (copied into the launch's arguments).  host_action_out (int32, or action_dim floats) and
+ * host_ticket (one word, may be NULL) must be PAGE-LOCKED host buffers (hipHostMalloc / torch
+ * pin_memory), which the kernel writes directly.  The kernel files the observation in state_row,
+ * computes exactly ppo_act's result for it (n = 1, same bits) and writes the
+ * action to action_row and to host_action_out, then `ticket` to *host_ticket; the call returns when
+ * it sees the ticket there (a spin on host memory: no stream wait).  `ticket` must differ from the
+ * word's current value (count calls, skipping nothing: any change will do).  With host_ticket ==
+ * NULL the stream is waited for instead.  One launch, no copy commands.  state_row / action_row /
+ * logprob_row / value_row are the rollout buffer's device rows for this step; value_row is
+ * complete in stream order (not necessarily when the call returns). */
 int ppo_act_host(const float* params, int state_dim, int action_dim, int continuous, float action_var,
                  const float* host_state, float* state_row, uint64_t seed, uint64_t rng_offset,
                  void* action_row, float* logprob_row, float* value_row, void* host_action_out,
-                 void* stream);
+                 unsigned* host_ticket, unsigned ticket, void* stream);
 
 /* ---- synthetic vectorised environment (measurement harness) ---------------------------------
  * One lockstep step of n_envs synthetic envs: observations ~ N(0,1), reward 1.0 (kind 0) or

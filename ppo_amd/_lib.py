@@ -4,14 +4,14 @@ There is no fallback: if the library is missing or a call fails, an exception is
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint, c_uint64, c_void_p
 
 import torch  # noqa: F401  (loads the HIP runtime the library binds to before dlopen)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # PPO_HIP_LIB: diagnostic builds of the same sources (python -m ppo_amd.build --variant ...)
 LIB_PATH = os.environ.get("PPO_HIP_LIB") or os.path.join(HERE, "libppo_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _SIGNATURES = {
     "ppo_hip_abi_version": (c_int, []),
@@ -40,7 +40,7 @@ _SIGNATURES = {
     "ppo_synth_env_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
                                    c_int64, c_int64, c_uint64, c_void_p]),
     "ppo_act_host": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_uint64, c_uint64,
-                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_void_p]),
     "ppo_cartpole_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_uint64, c_void_p]),
     "ppo_cartpole_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -966,7 +966,7 @@ extern "C" int ppo_update_epochs(float* params, int state_dim, int action_dim, i
     return 0;
 }
 
-extern "C" int ppo_hip_abi_version(void) { return 4; }
+extern "C" int ppo_hip_abi_version(void) { return 5; }
 
 extern "C" const char* ppo_hip_strerror(int code) {
     switch (code) {

@@ -527,18 +527,22 @@ class PPO:
     def _select_action_host(self, state):
         """The reference's protocol, one host state per call (PPO.py:175-198): the state goes through
         a page-locked staging buffer into its buffer row, the action comes back the same way, and the
-        whole step is one library call with one stream wait (ppo_act_host)."""
+        whole step is one library call that launches one kernel and spins on a ticket word the kernel
+        writes next to the action (ppo_act_host)."""
         if self._pin is None:
+            # one page-locked block: [action words (8)][ticket word]
             self._pin = (torch.empty(self.state_dim, dtype=torch.float32).pin_memory(),
-                         torch.empty(max(self.action_dim, 1), dtype=torch.float32).pin_memory())
+                         torch.zeros(16, dtype=torch.float32).pin_memory())
             self._pin_np = (self._pin[0].numpy(), self._pin[1].numpy(),
                             self._pin[1].numpy().view(np.int32))
-            self._pin_ptr = (self._pin[0].data_ptr(), self._pin[1].data_ptr())
+            self._pin_ptr = (self._pin[0].data_ptr(), self._pin[1].data_ptr(), self._pin[1].data_ptr() + 32)
+            self._ticket = 0
             self._act_host = _lib.lib().ppo_act_host
         self._pin_np[0][:] = state
         b = self.buffer
         lo = b.claim_step(1)
         seed, off = self._next_rng()
+        self._ticket = ticket = (self._ticket % 0x7fffffff) + 1
         pol = self.policy_old
         cont = self.has_continuous_action_space
         ra = b._row_addr
@@ -546,7 +550,7 @@ class PPO:
         rc = self._act_host(
             pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var_host,
             self._pin_ptr[0], ps + lo * ss, seed, off, pa + lo * sa, pl + lo * sl, pv + lo * sv,
-            self._pin_ptr[1], torch.cuda.current_stream().cuda_stream)
+            self._pin_ptr[1], self._pin_ptr[2], ticket, torch.cuda.current_stream().cuda_stream)
         if rc:
             _lib.check(rc)
         if cont:
