@@ -170,6 +170,29 @@ int ppo_act_host(const float* params, int state_dim, int action_dim, int continu
                  void* action_row, float* logprob_row, float* value_row, void* host_action_out,
                  unsigned* host_ticket, unsigned ticket, void* stream);
 
+/* The same step with the kernel launch taken off the critical path.  A session keeps one kernel
+ * launched AHEAD of its state: the kernel loads the weights, then polls a mailbox in page-locked
+ * host memory (owned by the session) until the next request is posted, serves it and ends; it gives
+ * up by itself after about wait_us microseconds, or when the session is drained.  _step posts the
+ * request (state, rows, seed / rng_offset and action_var as in ppo_act), launches the kernel for the
+ * step after, and returns when the action (int32, or action_dim floats) is in action_out (ordinary
+ * host memory); when it returns, all four rows of the step are visible to every stream.  The
+ * results are ppo_act's, bit for bit.  The session's kernels run on a stream of its own; the first
+ * kernel after _create / _drain is ordered behind the work already enqueued on after_stream.
+ * _drain withdraws the waiting kernel and waits for the session's stream: call it before the
+ * weights behind `params` change, before the rows' storage moves, and before exit (_destroy does).
+ * One session serves one caller thread.  No counterpart in the reference: PPO.py:175-198 pays a
+ * full launch per step. */
+typedef struct ppo_act_session ppo_act_session;
+int ppo_act_session_create(ppo_act_session** out, int state_dim, int action_dim, int continuous,
+                           int wait_us);
+int ppo_act_session_step(ppo_act_session* session, const float* params, float action_var,
+                         const float* host_state, uint64_t seed, uint64_t rng_offset, float* state_row,
+                         void* action_row, float* logprob_row, float* value_row, void* action_out,
+                         void* after_stream);
+int ppo_act_session_drain(ppo_act_session* session);
+int ppo_act_session_destroy(ppo_act_session* session);
+
 /* ---- synthetic vectorised environment (measurement harness) ---------------------------------
  * One lockstep step of n_envs synthetic envs: observations ~ N(0,1), reward 1.0 (kind 0) or
  * ~N(0,1) (kind 1), terminal ~ Bernoulli(p_terminal) or, when p_terminal < 0, exactly at steps

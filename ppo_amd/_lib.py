@@ -41,6 +41,11 @@ _SIGNATURES = {
                                    c_int64, c_int64, c_uint64, c_void_p]),
     "ppo_act_host": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_uint64, c_uint64,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_void_p]),
+    "ppo_act_session_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    "ppo_act_session_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppo_act_session_drain": (c_int, [c_void_p]),
+    "ppo_act_session_destroy": (c_int, [c_void_p]),
     "ppo_cartpole_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_uint64, c_void_p]),
     "ppo_cartpole_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppo_hip.so")
-SOURCES = ["scan.hip", "act.hip", "update.hip", "env.hip", "rollout.hip", "update_sym.hip"]
+SOURCES = ["scan.hip", "act.hip", "act_one.hip", "update.hip", "env.hip", "rollout.hip", "update_sym.hip"]
 HEADERS = ["ppo_common.h", "update_common.h", os.path.join("..", "..", "include", "ppo_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
          "-fhip-fp32-correctly-rounded-divide-sqrt"]

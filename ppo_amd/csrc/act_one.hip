@@ -1,0 +1,381 @@
+// select_action as train.py:176 calls it: ONE state per call, the action back on the host before the
+// env can step.  What counts here is the time from "state known" to "action known", not throughput.
+//
+// Kernel.  A tile kernel would stage 17 KB of weights into LDS to use one column of a 32-column
+// MFMA; here a wave per network holds one hidden unit per lane and reads its weight rows straight
+// from global memory.  The fp32 MFMA adds its k-slices as a chain of fmaf (one rounding each, lower
+// lane group first), so the same chain on the VALU, in the tile's unit order, gives the tile
+// kernels' result bit for bit:
+//   layer 1: inputs ascending, then the bias;  layer 2: bias first, then the units in the order
+//   0,4,1,5,2,6,3,7 | 8,12,...;  out layer: the four partial sums of out_layer_act.
+// The activation a lane needs from another lane comes by v_readlane (layer 2) or through 64 floats
+// of LDS (out layer).  Wave 0 = actor (+ head, sampling, the host copy of the action and the
+// completion ticket), wave 1 = critic.
+//
+// Two ways to hand it a state:
+//  * ppo_act_host: the state travels in the launch's arguments; the host spins on a ticket word in
+//    page-locked memory instead of waiting for the stream.
+//  * ppo_act_session_*: the launch itself leaves the critical path.  A kernel is launched BEFORE
+//    its state exists: it loads its weights, then polls a mailbox in page-locked host memory for
+//    the request (bounded: it gives up after about a millisecond, or when told to), serves it, and
+//    exits.  Each step posts its request and launches the kernel for the step after, so that launch
+//    overlaps the device's work on this step.  Every kernel serves at most one request and always
+//    terminates on its own; kernels of one session run on the session's own stream, one after the
+//    other, which is what lets them pass "last request served" through a device word.
+#include "ppo_common.h"
+#include <string.h>
+
+struct ActRequest {   // one 64-byte line; seq is written last (host) and read first (device)
+    float* state_row;
+    void* action_row;
+    float* logprob_row;
+    float* value_row;
+    uint64_t seed, rng_offset;
+    float action_var;
+    unsigned seq;
+    unsigned pad[2];
+};
+
+struct ActMailbox {   // page-locked host memory
+    ActRequest req;                 // host -> device
+    float state[64];                // host -> device
+    float action[8];                // device -> host (int32 in word 0 for a discrete policy)
+    unsigned ticket;                //   seq of the last request served
+    unsigned unserved;              //   kernels that gave up waiting so far (only grows)
+    unsigned pad[6];
+};
+
+struct OneState {   // the observation, passed by value: it reaches the device with the launch itself
+    float v[PPO_MAX_STATE_DIM + 1];
+};
+
+#define ACT_CANCEL_BIT 0x80000000u
+#define ACT_MAX_POLLS (1u << 16)
+
+template <class T>
+__device__ __forceinline__ T host_load(const T* p) {   // a load that always goes to the host's memory
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// mb == nullptr: serve (req, state) from the arguments now, report through host_action_out / host_ticket.
+// mb != nullptr: wait for request number words[0] + 1 in the mailbox (words: device memory,
+// [0] = last request served, [1] = kernels that gave up), serve it, report through the mailbox.
+template <bool CONT, int AMAX>
+__global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ params, int S, int A,
+                                                      ActRequest req, const OneState state,
+                                                      void* host_action_out, unsigned* host_ticket,
+                                                      ActMailbox* mb, unsigned* words,
+                                                      unsigned wait_ticks) {
+    // every multiply and add below is rounded as written (a prescale product must be rounded before
+    // it enters the chain, as the tile kernels' staged images are)
+#pragma clang fp contract(off)
+    __shared__ float h2s[2][HID];
+    __shared__ int go;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), u = threadIdx.x & 63;
+    const int aout = wave ? 1 : A;
+    const NetLayout PA = net_layout(0, S, A);
+    const NetLayout P = wave ? net_layout(PA.n, S, 1) : PA;
+
+    // weight rows of this lane's unit: issued up front (in the waiting form: before the state exists)
+    f32x4 w2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w2[i] = *reinterpret_cast<const f32x4*>(params + P.w2 + u * HID + 4 * i);
+    const float b1 = params[P.b1 + u], b2 = params[P.b2 + u];
+    float w1a[8];   // the first eight inputs' weights (all of them for most envs)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w1a[j] = j < S ? params[P.w1 + u * S + j] : 0.f;
+    // out layer: lane 4 a + g sums class g of output a (16 units, ascending)
+    const int oa = u >> 2, og = u & 3;
+    const bool out_lane = oa < aout;
+    float w3[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w3[i] = out_lane ? params[P.w3 + oa * HID + u16(og, i >> 2, i & 3)] : 0.f;
+    float b3[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) b3[a] = a < aout ? params[P.b3 + a] : 0.f;
+
+    unsigned expect = 0;
+    float xv = 0.f;
+    if (mb) {
+        expect = words[0] + 1;
+        if (threadIdx.x == 0) {
+            int g = 0;
+            const uint64_t t0 = wall_clock64();
+            for (unsigned it = 0; it < ACT_MAX_POLLS; ++it) {
+                const unsigned s = host_load(&mb->req.seq);
+                if (s == expect) { g = 1; break; }
+                if ((s & ACT_CANCEL_BIT) || wall_clock64() - t0 > wait_ticks) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            go = g;
+        }
+        __syncthreads();
+        if (!go) {   // nobody came: say so and leave
+            if (threadIdx.x == 0) {
+                const unsigned n = words[1] + 1;
+                words[1] = n;
+                __hip_atomic_store(&mb->unserved, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        req.state_row = host_load(&mb->req.state_row);
+        req.action_row = host_load(&mb->req.action_row);
+        req.logprob_row = host_load(&mb->req.logprob_row);
+        req.value_row = host_load(&mb->req.value_row);
+        req.seed = host_load(&mb->req.seed);
+        req.rng_offset = host_load(&mb->req.rng_offset);
+        req.action_var = host_load(&mb->req.action_var);
+        if (u < S) xv = host_load(&mb->state[u]);
+    } else {
+        if (u < S) xv = state.v[u];
+    }
+    if (wave == 0 && u < S) req.state_row[u] = xv;
+    const int xb = __float_as_int(xv);
+
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)   // a zero weight (input >= S) leaves z as it is
+        z = fmaf(w1a[j] * TANH_PRESCALE, __int_as_float(__builtin_amdgcn_readlane(xb, j)), z);
+    for (int k0 = 8; k0 < S; k0 += 8) {   // eight loads in flight
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = k0 + j < S ? params[P.w1 + u * S + k0 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            z = fmaf(w[j] * TANH_PRESCALE, __int_as_float(__builtin_amdgcn_readlane(xb, (k0 + j) & 63)), z);
+    }
+    z = b1 * TANH_PRESCALE + z;   // the tile's ones column: fmaf(b1s, 1, z), b1s rounded first
+    const int h1 = __float_as_int(tanh_prescaled(z));
+
+    float y = b2 * TANH_PRESCALE;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int k = 8 * (i >> 3) + ((i & 7) >> 1) + 4 * (i & 1);
+        y = fmaf(w2[k >> 2][k & 3] * TANH_PRESCALE, __int_as_float(__builtin_amdgcn_readlane(h1, k)), y);
+    }
+    h2s[wave][u] = tanh_prescaled(y);
+    __syncthreads();
+
+    float p = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p = fmaf(w3[i], h2s[wave][u16(og, i >> 2, i & 3)], p);
+    const int pb = __float_as_int(p);
+    float o[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        float v = 0.f;
+        if (a < aout) {
+            const float p0 = __int_as_float(__builtin_amdgcn_readlane(pb, 4 * a + 0));
+            const float p1 = __int_as_float(__builtin_amdgcn_readlane(pb, 4 * a + 1));
+            const float p2 = __int_as_float(__builtin_amdgcn_readlane(pb, 4 * a + 2));
+            const float p3 = __int_as_float(__builtin_amdgcn_readlane(pb, 4 * a + 3));
+            v = ((p0 + p1) + (p2 + p3)) + b3[a];
+        }
+        o[a] = v;
+    }
+    float logp = 0.f, ent, act_c[AMAX];
+    int action = 0;
+    if (wave) {
+        if (u == 0) req.value_row[0] = o[0];
+    } else {
+        policy_head_act<CONT, AMAX, true>(o, A, req.action_var, req.seed, req.rng_offset, 0, true, u,
+                                          req.action_row, logp, ent, action, act_c);
+        if (u == 0) req.logprob_row[0] = logp;
+    }
+    __syncthreads();   // the critic's row is written too: the ticket below vouches for the whole step
+    if (threadIdx.x == 0) {
+        void* const out = mb ? (void*)mb->action : host_action_out;
+        if constexpr (CONT) {
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) if (k < A) reinterpret_cast<float*>(out)[k] = act_c[k];
+        } else {
+            reinterpret_cast<int*>(out)[0] = action;
+        }
+        unsigned* const tick = mb ? &mb->ticket : host_ticket;
+        if (mb) words[0] = expect;
+        if (tick) {
+            __threadfence_system();
+            __hip_atomic_store(tick, mb ? expect : req.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+static int launch_one(const float* params, int S, int A, int continuous, const ActRequest& req,
+                      const OneState& state, void* host_action_out, unsigned* host_ticket, ActMailbox* mb,
+                      unsigned* words, unsigned wait_ticks, hipStream_t st) {
+#define ACT_ONE(C, AM)                                                                           \
+    act_one_kernel<C, AM><<<1, 128, 0, st>>>(params, S, A, req, state, host_action_out, host_ticket, mb, \
+                                             words, wait_ticks)
+    if (continuous) {
+        if (A <= 4) ACT_ONE(true, 4); else ACT_ONE(true, 8);
+    } else {
+        if (A <= 4) ACT_ONE(false, 4); else ACT_ONE(false, 8);
+    }
+#undef ACT_ONE
+    return (int)hipGetLastError();
+}
+
+// Spin until *word == want; every so often ask the stream, so that a kernel that ended without
+// writing the word (a fault) surfaces as its error instead of a hang.
+static int spin_for(const unsigned* word, unsigned want, hipStream_t st) {
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return 0;
+        if ((spins & 0xffff) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return __atomic_load_n(word, __ATOMIC_ACQUIRE) == want ? 0 : (int)hipErrorUnknown;
+            if (q != hipErrorNotReady) return (int)q;
+        }
+    }
+}
+
+extern "C" int ppo_act_host(const float* params, int state_dim, int action_dim, int continuous,
+                            float action_var, const float* host_state, float* state_row,
+                            uint64_t seed, uint64_t rng_offset, void* action_row, float* logprob_row,
+                            float* value_row, void* host_action_out, unsigned* host_ticket,
+                            unsigned ticket, void* stream) {
+    if (!params || !host_state || !state_row || !host_action_out || !action_row || !logprob_row || !value_row)
+        return PPO_E_BADARG;
+    if (state_dim < 1 || state_dim > PPO_MAX_STATE_DIM || action_dim < 1 || action_dim > PPO_MAX_ACTION_DIM)
+        return PPO_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (host_ticket && __atomic_load_n(host_ticket, __ATOMIC_ACQUIRE) == ticket) return PPO_E_BADARG;
+    OneState state;
+    memcpy(state.v, host_state, sizeof(float) * state_dim);
+    ActRequest req{};
+    req.state_row = state_row; req.action_row = action_row; req.logprob_row = logprob_row;
+    req.value_row = value_row; req.seed = seed; req.rng_offset = rng_offset; req.action_var = action_var;
+    req.seq = ticket;
+    const int rc = launch_one(params, state_dim, action_dim, continuous, req, state, host_action_out,
+                              host_ticket, nullptr, nullptr, 0, st);
+    if (rc) return rc;
+    if (!host_ticket) return (int)hipStreamSynchronize(st);
+    return spin_for(host_ticket, ticket, st);
+}
+
+// ---------------------------------------------------------------------------- sessions
+struct ppo_act_session {
+    ActMailbox* mb;
+    unsigned* words;          // device: [0] last request served, [1] kernels that gave up
+    hipStream_t stream;       // the session's own stream (non-blocking)
+    hipEvent_t after;         // orders the first kernel after a drain behind the caller's stream
+    int S, A, continuous;
+    const float* params;      // weights the waiting kernels were launched with
+    unsigned seq;             // last request posted
+    unsigned seen_unserved;
+    int inflight;             // kernels launched and not yet known to have ended
+    unsigned wait_ticks;
+};
+
+static int session_launch(ppo_act_session* s) {
+    const ActRequest none{};
+    const OneState no_state{};
+    const int rc = launch_one(s->params, s->S, s->A, s->continuous, none, no_state, nullptr, nullptr, s->mb,
+                              s->words, s->wait_ticks, s->stream);
+    if (!rc) ++s->inflight;
+    return rc;
+}
+
+extern "C" int ppo_act_session_create(ppo_act_session** out, int state_dim, int action_dim, int continuous,
+                                      int wait_us) {
+    if (!out || wait_us < 1 || wait_us > 100000) return PPO_E_BADARG;
+    if (state_dim < 1 || state_dim > PPO_MAX_STATE_DIM || action_dim < 1 || action_dim > PPO_MAX_ACTION_DIM)
+        return PPO_E_UNSUPPORTED;
+    ppo_act_session* s = new ppo_act_session();
+    s->S = state_dim; s->A = action_dim; s->continuous = continuous;
+    s->wait_ticks = (unsigned)wait_us * 100u;   // wall_clock64 counts at 100 MHz
+    hipError_t e = hipHostMalloc((void**)&s->mb, sizeof(ActMailbox), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->words, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(s->words, 0, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->after, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (s->mb) (void)hipHostFree(s->mb);
+        if (s->words) (void)hipFree(s->words);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+        delete s;
+        return (int)e;
+    }
+    memset(s->mb, 0, sizeof(ActMailbox));
+    *out = s;
+    return 0;
+}
+
+// Withdraw the waiting kernel (if any) and wait until every kernel of the session has ended: after
+// this the rows written so far are visible to any stream, and the weights may change.
+extern "C" int ppo_act_session_drain(ppo_act_session* s) {
+    if (!s) return PPO_E_BADARG;
+    if (s->inflight) __atomic_store_n(&s->mb->req.seq, s->seq | ACT_CANCEL_BIT, __ATOMIC_RELEASE);
+    const hipError_t e = hipStreamSynchronize(s->stream);
+    s->inflight = 0;
+    s->seen_unserved = __atomic_load_n(&s->mb->unserved, __ATOMIC_ACQUIRE);
+    return (int)e;
+}
+
+extern "C" int ppo_act_session_destroy(ppo_act_session* s) {
+    if (!s) return 0;
+    const int rc = ppo_act_session_drain(s);
+    (void)hipStreamDestroy(s->stream);
+    (void)hipEventDestroy(s->after);
+    (void)hipHostFree(s->mb);
+    (void)hipFree(s->words);
+    delete s;
+    return rc;
+}
+
+extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, float action_var,
+                                    const float* host_state, uint64_t seed, uint64_t rng_offset,
+                                    float* state_row, void* action_row, float* logprob_row,
+                                    float* value_row, void* action_out, void* after_stream) {
+    if (!s || !params || !host_state || !state_row || !action_row || !logprob_row || !value_row || !action_out)
+        return PPO_E_BADARG;
+    if (s->params != params || s->seq >= 0x7ffffff0u) {   // other weights (or the counter is used up): start over
+        const int rc = ppo_act_session_drain(s);
+        if (rc) return rc;
+        s->params = params;
+        if (s->seq >= 0x7ffffff0u) {
+            s->seq = 0;
+            const hipError_t e = hipMemset(s->words, 0, sizeof(unsigned));
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    ActMailbox* const mb = s->mb;
+    const unsigned k = ++s->seq;
+    memcpy(mb->state, host_state, sizeof(float) * s->S);
+    mb->req.state_row = state_row; mb->req.action_row = action_row; mb->req.logprob_row = logprob_row;
+    mb->req.value_row = value_row; mb->req.seed = seed; mb->req.rng_offset = rng_offset;
+    mb->req.action_var = action_var;
+    __atomic_store_n(&mb->req.seq, k, __ATOMIC_RELEASE);
+    int rc = 0;
+    if (s->inflight == 0) {                           // nobody is waiting for this request
+        // first kernel since the drain: it must see what the caller's stream did meanwhile (new weights)
+        hipError_t e = hipEventRecord(s->after, (hipStream_t)after_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->after, 0);
+        if (e != hipSuccess) return (int)e;
+        rc = session_launch(s);
+    }
+    if (!rc) rc = session_launch(s);                  // the kernel for the NEXT request: overlaps this one
+    if (rc) return rc;
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(&mb->ticket, __ATOMIC_ACQUIRE) == k) break;
+        const unsigned gave_up = __atomic_load_n(&mb->unserved, __ATOMIC_ACQUIRE);
+        if (gave_up != s->seen_unserved) {            // waiting kernels that left before the request came
+            s->inflight -= (int)(gave_up - s->seen_unserved);
+            s->seen_unserved = gave_up;
+            if (s->inflight <= 0) {
+                s->inflight = 0;
+                if ((rc = session_launch(s))) return rc;
+            }
+        }
+        if ((spins & 0xffff) == 0) {
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
+            if (q == hipSuccess && __atomic_load_n(&mb->ticket, __ATOMIC_ACQUIRE) != k &&
+                __atomic_load_n(&mb->unserved, __ATOMIC_ACQUIRE) == s->seen_unserved)
+                return (int)hipErrorUnknown;          // every kernel ended, none served, none gave up
+        }
+    }
+    --s->inflight;                                     // the kernel that served k
+    memcpy(action_out, mb->action, sizeof(float) * (s->continuous ? s->A : 1));
+    return 0;
+}

@@ -136,6 +136,7 @@ class RolloutBuffer:
         self._S, self._A, self._cont = state_dim, action_dim, continuous
         self._dev = dev if dev is not None else device
         self._cap = 0
+        self._before_move = None   # called before the columns' storage is reallocated
         self._count = {"actions": 0, "states": 0, "logprobs": 0, "state_values": 0,
                        "rewards": 0, "is_terminals": 0}
         self._n_envs = 1
@@ -159,6 +160,8 @@ class RolloutBuffer:
     def reserve(self, rows):
         if rows <= self._cap:
             return
+        if self._before_move is not None:
+            self._before_move()   # kernels that still write rows of the old storage finish first
         cap = max(rows, 2 * self._cap, 1024)
         for name, (shp, dt) in self._shapes().items():
             new = torch.empty((cap,) + shp, dtype=dt, device=self._dev)
@@ -296,6 +299,13 @@ class ActorCritic(nn.Module):
             off += n
         assert off == total
         self.flat = flat
+
+    _before_write = None   # called before load_state_dict overwrites the parameters
+
+    def load_state_dict(self, *args, **kwargs):
+        if self._before_write is not None:
+            self._before_write()
+        return super().load_state_dict(*args, **kwargs)
 
     def _apply(self, fn, recurse=True):
         # The parameters are views into one flat fp32 vector on the engine's device; .to(device)
@@ -452,7 +462,10 @@ class PPO:
 
         # engine state
         self._rng_seed = None      # drawn from torch's generator on first use (honours torch.manual_seed)
-        self._pin = None           # page-locked staging of the single-env protocol, made on first use
+        self._act_session = None   # single-env protocol: session of kernels launched ahead, made on first use
+        self._pin = None           # ... or, with PPO_ACT_SESSION=0, the page-locked staging of ppo_act_host
+        self.buffer._before_move = self._act_drain
+        self.policy_old._before_write = self._act_drain
         self._rng_offset = 0
         self._ws = None
         self._moments = torch.zeros(3, dtype=torch.float64, device=device)
@@ -524,37 +537,67 @@ class PPO:
             return act.detach().cpu().numpy().flatten()
         return int(act.item())
 
+    def _act_drain(self):
+        """Withdraw the act kernel that waits for the next single state, and wait for the session's
+        stream: required before policy_old's weights change or the buffer's storage moves."""
+        if self._act_session is not None:
+            _lib.check(self._act_drain_fn(self._act_session))
+
+    def __del__(self):
+        try:
+            if self._act_session is not None:
+                _lib.lib().ppo_act_session_destroy(self._act_session)
+                self._act_session = None
+        except Exception:
+            pass
+
     def _select_action_host(self, state):
-        """The reference's protocol, one host state per call (PPO.py:175-198): the state goes through
-        a page-locked staging buffer into its buffer row, the action comes back the same way, and the
-        whole step is one library call that launches one kernel and spins on a ticket word the kernel
-        writes next to the action (ppo_act_host)."""
+        """The reference's protocol, one host state per call (PPO.py:175-198).  Default: a session
+        of act kernels launched one step ahead, which wait for the state in a page-locked mailbox
+        (ppo_act_session_step) - no launch and no stream wait between "state known" and "action
+        known".  PPO_ACT_SESSION=0: one launch per call with the state in its arguments, and a spin
+        on a ticket word the kernel writes next to the action (ppo_act_host)."""
         if self._pin is None:
-            # one page-locked block: [action words (8)][ticket word]
-            self._pin = (torch.empty(self.state_dim, dtype=torch.float32).pin_memory(),
-                         torch.zeros(16, dtype=torch.float32).pin_memory())
-            self._pin_np = (self._pin[0].numpy(), self._pin[1].numpy(),
-                            self._pin[1].numpy().view(np.int32))
-            self._pin_ptr = (self._pin[0].data_ptr(), self._pin[1].data_ptr(), self._pin[1].data_ptr() + 32)
+            L = _lib.lib()
+            # [state (64 words)][action words (8)][ticket word]; page-locked for ppo_act_host's sake
+            self._pin = torch.zeros(64 + 16, dtype=torch.float32).pin_memory()
+            a = self._pin.numpy()
+            self._pin_np = (a[:self.state_dim], a[64:64 + self.action_dim], a[64:65].view(np.int32))
+            p = self._pin.data_ptr()
+            self._pin_ptr = (p, p + 256, p + 256 + 32)
             self._ticket = 0
-            self._act_host = _lib.lib().ppo_act_host
+            self._act_host = L.ppo_act_host
+            if os.environ.get("PPO_ACT_SESSION", "1") != "0":
+                h = ctypes.c_void_p()
+                _lib.check(L.ppo_act_session_create(ctypes.byref(h), self.state_dim, self.action_dim,
+                                                    int(self.has_continuous_action_space),
+                                                    int(os.environ.get("PPO_ACT_WAIT_US", "1000"))))
+                self._act_session = h
+                self._act_step_fn = L.ppo_act_session_step
+                self._act_drain_fn = L.ppo_act_session_drain
         self._pin_np[0][:] = state
         b = self.buffer
         lo = b.claim_step(1)
         seed, off = self._next_rng()
-        self._ticket = ticket = (self._ticket % 0x7fffffff) + 1
         pol = self.policy_old
         cont = self.has_continuous_action_space
         ra = b._row_addr
         (ps, ss), (pa, sa), (pl, sl), (pv, sv) = ra["states"], ra["actions"], ra["logprobs"], ra["state_values"]
-        rc = self._act_host(
-            pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var_host,
-            self._pin_ptr[0], ps + lo * ss, seed, off, pa + lo * sa, pl + lo * sl, pv + lo * sv,
-            self._pin_ptr[1], self._pin_ptr[2], ticket, torch.cuda.current_stream().cuda_stream)
+        if self._act_session is not None:
+            rc = self._act_step_fn(
+                self._act_session, pol.flat.data_ptr(), pol._var_host, self._pin_ptr[0], seed, off,
+                ps + lo * ss, pa + lo * sa, pl + lo * sl, pv + lo * sv, self._pin_ptr[1],
+                torch.cuda.current_stream().cuda_stream)
+        else:
+            self._ticket = ticket = (self._ticket % 0x7fffffff) + 1
+            rc = self._act_host(
+                pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var_host,
+                self._pin_ptr[0], ps + lo * ss, seed, off, pa + lo * sa, pl + lo * sl, pv + lo * sv,
+                self._pin_ptr[1], self._pin_ptr[2], ticket, torch.cuda.current_stream().cuda_stream)
         if rc:
             _lib.check(rc)
         if cont:
-            return self._pin_np[1][:self.action_dim].copy()
+            return self._pin_np[1].copy()
         return int(self._pin_np[2][0])
 
     def act_inplace(self, n_envs):
@@ -638,6 +681,7 @@ class PPO:
 
     def update(self, debug=False):
         _require_gpu()
+        self._act_drain()
         L = _lib.lib()
         b = self.buffer
         st = _lib.stream_ptr()

@@ -4,6 +4,8 @@ import ctypes
 import json
 import os
 
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -533,11 +535,17 @@ def test_synthetic_rollout_equals_per_step_calls(eng, cont, S, A, N, T):
         assert torch.equal(a, bb), c
 
 
+@pytest.mark.parametrize("mode", ["session", "session_slow_env", "ticket"])
 @pytest.mark.parametrize("cont", [False, True])
-def test_single_state_host_path_equals_batched_rows(eng, cont):
-    """select_action(np.ndarray[S]) (page-locked staging, ppo_act_host) stores exactly what the
-    batched call stores for the same states, and returns the reference's Python types."""
+def test_single_state_host_path_equals_batched_rows(eng, cont, mode, monkeypatch):
+    """select_action(np.ndarray[S]) stores exactly what the batched call stores for the same states
+    (the one-unit-per-lane VALU kernel reproduces the MFMA tile's fmaf chain), and returns the
+    reference's Python types.  session: kernels launched one step ahead that wait for the state in a
+    mailbox; session_slow_env: the env takes longer than the kernel waits, so every waiting kernel
+    gives up and the step is served by a fresh one; ticket: one launch per call (ppo_act_host)."""
     ppo, _ = eng
+    monkeypatch.setenv("PPO_ACT_SESSION", "0" if mode == "ticket" else "1")
+    monkeypatch.setenv("PPO_ACT_WAIT_US", "200" if mode == "session_slow_env" else "1000")
     S, A = (24, 4) if cont else (8, 4)
     xs = np.random.default_rng(8).standard_normal((6, S)).astype(np.float32)
     cols = ("states", "actions", "logprobs", "state_values")
@@ -546,14 +554,29 @@ def test_single_state_host_path_equals_batched_rows(eng, cont):
         torch.manual_seed(21)
         agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, cont, 0.4 if cont else None)
         outs = []
-        for x in xs:
+        for i, x in enumerate(xs):
             if host:
+                if mode == "session_slow_env" and i:
+                    time.sleep(0.003)
                 a = agent.select_action(x.astype(np.float64))       # gym hands over float64
                 assert isinstance(a, np.ndarray) and a.dtype == np.float32 if cont else isinstance(a, int)
                 outs.append(np.asarray(a))
             else:
                 outs.append(agent.select_action(torch.from_numpy(x[None]).cuda()).cpu().numpy()[0])
+        assert (agent._act_session is not None) == (host and mode != "ticket")
         got.append(([agent.buffer.rows(c, 0, 6).clone() for c in cols], np.array(outs)))
+        if host:
+            # an update in between drains the session (new weights), then the protocol goes on
+            for _ in range(6):
+                agent.buffer.rewards.append(1.0)
+                agent.buffer.is_terminals.append(False)
+            agent.update()
+            a2 = agent.select_action(xs[0])
+            ref = agent.policy_old.act(torch.from_numpy(xs[0]).cuda(), _seed=agent._rng_seed,
+                                       _offset=agent._rng_offset)
+            assert np.array_equal(np.asarray(a2).reshape(-1), ref[0].cpu().numpy().reshape(-1))
+            assert torch.equal(agent.buffer.rows("logprobs", 0, 1), ref[1].reshape(1))
+            assert torch.equal(agent.buffer.rows("state_values", 0, 1), ref[2].reshape(1))
     for c, a, b in zip(cols, got[0][0], got[1][0]):
         assert torch.equal(a, b), c
     assert np.array_equal(got[0][1], got[1][1])

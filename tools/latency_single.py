@@ -40,32 +40,24 @@ for _ in range(n):
 dt = (time.perf_counter() - t0) / n
 print(f"full step (select_action + device CartPole step + appends): {dt * 1e6:.1f} us ({1 / dt:.0f} steps/s)")
 
-# ---- where the time of one select_action goes (discrete S=4 A=2)
-from ppo_amd import _lib
-agent = PPO(4, 2, 3e-4, 1e-3, 0.99, 4, 0.2, False, None)
-agent.buffer.reserve(n + 64)
-x = np.random.default_rng(0).standard_normal(4)
-agent.select_action(x)
-real = agent._act_host
-agent._act_host = lambda *a: 0
-t0 = time.perf_counter()
-for _ in range(n):
-    agent.select_action(x)
-dt_py = (time.perf_counter() - t0) / n
-agent._act_host = real
-agent.buffer.clear()
-b = agent.buffer
-lo = b.claim_step(n)
-st = torch.cuda.current_stream().cuda_stream
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-rows = [b.rows(c, lo, lo + n) for c in ("states", "actions", "logprobs", "state_values")]
-L = _lib.lib()
-torch.cuda.synchronize()
-e0.record()
-for i in range(n):
-    L.ppo_act(agent.policy_old.flat.data_ptr(), 4, 2, 0, 0.0, rows[0].data_ptr(), 1, 1, i,
-              rows[1].data_ptr(), rows[2].data_ptr(), rows[3].data_ptr(), st)
-e1.record()
-torch.cuda.synchronize()
-print(f"breakdown: python wrapper without the library call {dt_py * 1e6:.1f} us; "
-      f"act kernel back to back (n = 1) {e0.elapsed_time(e1) / n * 1e3:.1f} us per launch")
+# ---- the same with host work between the calls, as an env's step() would be (the waiting kernel of a
+# session is then already polling when the next state arrives)
+def spin(us):
+    t = time.perf_counter() + us * 1e-6
+    while time.perf_counter() < t:
+        pass
+
+for work_us in (10, 30):
+    agent = PPO(4, 2, 3e-4, 1e-3, 0.99, 4, 0.2, False, None)
+    agent.buffer.reserve(n + 64)
+    x = np.random.default_rng(0).standard_normal(4)
+    for _ in range(50):
+        agent.select_action(x)
+    tot = 0.0
+    for _ in range(n):
+        spin(work_us)
+        t0 = time.perf_counter()
+        agent.select_action(x)
+        tot += time.perf_counter() - t0
+    print(f"select_action with {work_us} us of host work between calls: {tot / n * 1e6:.1f} us per call")
+    agent._act_drain()
