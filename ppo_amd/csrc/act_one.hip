@@ -18,7 +18,7 @@
 //  * ppo_act_session_*: the launch itself leaves the critical path.  A kernel is launched BEFORE
 //    its state exists: it loads its weights, then polls a mailbox in page-locked host memory for
 //    the request (bounded: it gives up after about a millisecond, or when told to), serves it, and
-//    exits.  Each step posts its request and launches the kernel for the step after, so that launch
+//    exits.  Request numbers are 1 .. 2^31 - 1; the top bit of the mailbox word withdraws the waiter.  Each step posts its request and launches the kernel for the step after, so that launch
 //    overlaps the device's work on this step.  Every kernel serves at most one request and always
 //    terminates on its own; kernels of one session run on the session's own stream, one after the
 //    other, which is what lets them pass "last request served" through a device word.
@@ -58,8 +58,8 @@ __device__ __forceinline__ T host_load(const T* p) {   // a load that always goe
 }
 
 // mb == nullptr: serve (req, state) from the arguments now, report through host_action_out / host_ticket.
-// mb != nullptr: wait for request number words[0] + 1 in the mailbox (words: device memory,
-// [0] = last request served, [1] = kernels that gave up), serve it, report through the mailbox.
+// mb != nullptr: wait until the mailbox holds a request number other than words[0] (words: device
+// memory, [0] = last request served, [1] = kernels that gave up), serve it, report through the mailbox.
 template <bool CONT, int AMAX>
 __global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ params, int S, int A,
                                                       ActRequest req, const OneState state,
@@ -97,19 +97,21 @@ __global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ 
     unsigned expect = 0;
     float xv = 0.f;
     if (mb) {
-        expect = words[0] + 1;
         if (threadIdx.x == 0) {
-            int g = 0;
+            const unsigned served = words[0];
+            unsigned g = 0;
             const uint64_t t0 = wall_clock64();
             for (unsigned it = 0; it < ACT_MAX_POLLS; ++it) {
                 const unsigned s = host_load(&mb->req.seq);
-                if (s == expect) { g = 1; break; }
-                if ((s & ACT_CANCEL_BIT) || wall_clock64() - t0 > wait_ticks) break;
+                if (s & ACT_CANCEL_BIT) break;
+                if (s != served) { g = s; break; }
+                if (wall_clock64() - t0 > wait_ticks) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            go = g;
+            go = (int)g;
         }
         __syncthreads();
+        expect = (unsigned)go;
         if (!go) {   // nobody came: say so and leave
             if (threadIdx.x == 0) {
                 const unsigned n = words[1] + 1;
