@@ -301,7 +301,7 @@ def main():
             "phases": phases,
             "final_loss": float(agent.last_loss[-1].item()),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only: other ranks must not wait for it
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if grouped:
