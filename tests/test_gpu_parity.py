@@ -582,6 +582,30 @@ def test_single_state_host_path_equals_batched_rows(eng, cont, mode, monkeypatch
     assert np.array_equal(got[0][1], got[1][1])
 
 
+def test_single_state_session_survives_buffer_growth(eng):
+    """1100 single-state steps cross the buffer's first capacity (1024 rows): the session is drained
+    before the columns move, the rows written before and after the move are all there, and equal
+    the batched call's."""
+    ppo, _ = eng
+    S, A, n = 4, 2, 1100
+    xs = np.random.default_rng(3).standard_normal((n, S)).astype(np.float32)
+    got = []
+    for host in (True, False):
+        torch.manual_seed(5)
+        agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, False, None)
+        if host:
+            acts = [agent.select_action(x) for x in xs]
+        else:
+            acts = []
+            for i in range(0, n, 1):   # one row per call, as the host path numbers its draws
+                acts.append(int(agent.select_action(torch.from_numpy(xs[i:i + 1]).cuda())[0]))
+        got.append((np.array(acts), [agent.buffer.rows(c, 0, n).clone()
+                                     for c in ("states", "actions", "logprobs", "state_values")]))
+    assert np.array_equal(got[0][0], got[1][0])
+    for a, b in zip(got[0][1], got[1][1]):
+        assert torch.equal(a, b)
+
+
 def test_batched_update_equals_flat_with_row_end_terminals(eng):
     """N lockstep envs x T steps through the tensor-valued buffer facade == the oracle's flat
     update of the env-major concatenation with every row end flagged terminal."""
