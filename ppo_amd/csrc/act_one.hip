@@ -60,15 +60,15 @@ __device__ __forceinline__ T host_load(const T* p) {   // a load that always goe
 // mb == nullptr: serve (req, state) from the arguments now, report through host_action_out / host_ticket.
 // mb != nullptr: wait until the mailbox holds a request number other than words[0] (words: device
 // memory, [0] = last request served, [1] = kernels that gave up), serve it, report through the mailbox.
-template <bool CONT, int AMAX>
-__global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ params, int S, int A,
-                                                      ActRequest req, const OneState state,
-                                                      void* host_action_out, unsigned* host_ticket,
-                                                      ActMailbox* mb, unsigned* words,
-                                                      unsigned wait_ticks) {
+template <bool CONT, int AMAX, bool WAIT>
+__device__ __forceinline__ void act_one_body(const float* __restrict__ params, int S, int A,
+                                             ActRequest req, const OneState* state,
+                                             void* host_action_out, unsigned* host_ticket,
+                                             ActMailbox* mb_arg, unsigned* words, unsigned wait_ticks) {
     // every multiply and add below is rounded as written (a prescale product must be rounded before
     // it enters the chain, as the tile kernels' staged images are)
 #pragma clang fp contract(off)
+    ActMailbox* const mb = WAIT ? mb_arg : nullptr;
     __shared__ float h2s[2][HID];
     __shared__ int go;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), u = threadIdx.x & 63;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ 
 
     unsigned expect = 0;
     float xv = 0.f;
-    if (mb) {
+    if constexpr (WAIT) {
         if (threadIdx.x == 0) {
             const unsigned served = words[0];
             unsigned g = 0;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ 
         req.action_var = host_load(&mb->req.action_var);
         if (u < S) xv = host_load(&mb->state[u]);
     } else {
-        if (u < S) xv = state.v[u];
+        if (u < S) xv = state->v[u];
     }
     if (wave == 0 && u < S) req.state_row[u] = xv;
     const int xb = __float_as_int(xv);
@@ -203,16 +203,31 @@ __global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ 
     }
 }
 
+// Two entry points of the same body: the immediate form carries request and state in its arguments
+// (320 bytes); the waiting form's launch is on the caller's critical path, so it carries 40.
+template <bool CONT, int AMAX>
+__global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ params, int S, int A,
+                                                      const ActRequest req, const OneState state,
+                                                      void* host_action_out, unsigned* host_ticket) {
+    act_one_body<CONT, AMAX, false>(params, S, A, req, &state, host_action_out, host_ticket, nullptr, nullptr, 0);
+}
+
+template <bool CONT, int AMAX>
+__global__ __launch_bounds__(128) void act_wait_kernel(const float* __restrict__ params, int S, int A,
+                                                       ActMailbox* mb, unsigned* words, unsigned wait_ticks) {
+    act_one_body<CONT, AMAX, true>(params, S, A, ActRequest{}, nullptr, nullptr, nullptr, mb, words, wait_ticks);
+}
+
 static int launch_one(const float* params, int S, int A, int continuous, const ActRequest& req,
                       const OneState& state, void* host_action_out, unsigned* host_ticket, ActMailbox* mb,
                       unsigned* words, unsigned wait_ticks, hipStream_t st) {
-#define ACT_ONE(C, AM)                                                                           \
-    act_one_kernel<C, AM><<<1, 128, 0, st>>>(params, S, A, req, state, host_action_out, host_ticket, mb, \
-                                             words, wait_ticks)
+#define ACT_ONE(C, AM)                                                                              \
+    if (mb) act_wait_kernel<C, AM><<<1, 128, 0, st>>>(params, S, A, mb, words, wait_ticks);              \
+    else act_one_kernel<C, AM><<<1, 128, 0, st>>>(params, S, A, req, state, host_action_out, host_ticket)
     if (continuous) {
-        if (A <= 4) ACT_ONE(true, 4); else ACT_ONE(true, 8);
+        if (A <= 4) { ACT_ONE(true, 4); } else { ACT_ONE(true, 8); }
     } else {
-        if (A <= 4) ACT_ONE(false, 4); else ACT_ONE(false, 8);
+        if (A <= 4) { ACT_ONE(false, 4); } else { ACT_ONE(false, 8); }
     }
 #undef ACT_ONE
     return (int)hipGetLastError();
