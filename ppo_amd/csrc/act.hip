@@ -1,8 +1,9 @@
 // Lockstep batched act() / evaluate() forward, and the synthetic vectorised env step.
-// One wave = 32 states; both MLPs run on the fp32 MFMA tile of ppo_common.h.
+// One wave = 16 or 32 states; both MLPs run on the fp32 MFMA tiles of ppo_common.h.
 #include "ppo_common.h"
+#include <stdlib.h>
 
-template <bool CONT, int AMAX, bool SAMPLE>
+template <bool CONT, int AMAX, bool SAMPLE, int TM>
 __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ params, int S, int A,
                                                   float action_var,
                                                   const float* __restrict__ states, int64_t n,
@@ -13,37 +14,35 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
                                                   float* __restrict__ entropy,
                                                   float* __restrict__ states_copy,
                                                   void* __restrict__ actions_dup) {
-    // states_copy (optional): the observations are also written there (the rollout buffer's rows when
-    // `states` is a page-locked host buffer); actions_dup (optional): second destination of the
-    // sampled actions (a page-locked host buffer the caller reads after the stream has drained).
-    // Even workgroups run the actor on four 32-sample tiles, odd ones the critic on the same
+    // states_copy (optional): the observations are also written there; actions_dup (optional):
+    // second destination of the sampled actions.
+    // Even workgroups run the actor on four TM-sample tiles, odd ones the critic on the same
     // tiles: each stages only its own network into LDS and the two halves of a step run side by side.
+    // TM = 16 (16x16x4 MFMA) halves the step's dependent chain and is used for small batches, TM = 32
+    // amortises the image fill over twice the samples; the results are the same bits.
     extern __shared__ __align__(16) float smem[];
     const NetLayout PA = net_layout(0, S, A);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int64_t m = ((int64_t)(blockIdx.x >> 1) * 4 + wave) * TILE_M + c;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane / TM, c = lane % TM;
+    const int64_t m = ((int64_t)(blockIdx.x >> 1) * 4 + wave) * TM + c;
     const bool valid = m < n;
-    f32x16 H1[2], H2[2];
+    const RowFromGlobal x{states, S, m, valid};
+    TileNet<TM> net;
     if (blockIdx.x & 1) {
         const NetLayout PC = net_layout(PA.n, S, 1);
-        const NetLds LC = carve_net_lds(smem, S, 1, false);
-        fill_net_lds(LC, params, PC, S, 1, 1, false);
+        net.stage(smem, params, PC, S, 1, 1);
         __syncthreads();
-        mlp_fwd_tile(LC, states, S, m, valid, c, h, H1, H2);
         float v[1];
-        out_layer_act<1>(LC, 1, H2, h, v);
+        net.template forward<1>(S, 1, x, lane, v);
         if (valid && h == 0 && values) values[m] = v[0];
         if (states_copy && valid && h == 0)
             for (int k = 0; k < S; ++k) states_copy[m * S + k] = states[m * S + k];
         return;
     }
-    const NetLds LA = carve_net_lds(smem, S, AMAX, false);
-    fill_net_lds(LA, params, PA, S, A, AMAX, false);
+    net.stage(smem, params, PA, S, A, AMAX);
     __syncthreads();
 
-    mlp_fwd_tile(LA, states, S, m, valid, c, h, H1, H2);
     float o[AMAX];
-    out_layer_act<AMAX>(LA, A, H2, h, o);
+    net.template forward<AMAX>(S, A, x, lane, o);
 
     float logp, ent, act_c[AMAX];
     int action;
@@ -64,6 +63,17 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ para
     }
 }
 
+// 16-sample tiles while the launch is latency-bound (the chip is far from full), 32-sample tiles
+// beyond; PPO_ACT_TILE=16|32 overrides.
+static int act_tile(int64_t n) {
+    static const int forced = [] {
+        const char* e = getenv("PPO_ACT_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 16 || forced == 32) return forced;
+    return n <= 8192 ? 16 : 32;
+}
+
 template <bool SAMPLE>
 static int launch_act(const float* params, int S, int A, int continuous, float action_var,
                       const float* states, int64_t n, uint64_t seed, uint64_t rng_offset,
@@ -72,29 +82,32 @@ static int launch_act(const float* params, int S, int A, int continuous, float a
     if (!params || !states || !actions || n <= 0) return PPO_E_BADARG;
     if (S < 1 || S > PPO_MAX_STATE_DIM || A < 1 || A > PPO_MAX_ACTION_DIM) return PPO_E_UNSUPPORTED;
     const int amax = A <= 4 ? 4 : 8;
-    const size_t lds = (size_t)net_lds_floats(S, amax, false) * 4;  // the actor's image is the larger
-    const int64_t tiles = (n + TILE_M - 1) / TILE_M;
+    const int tm = act_tile(n);
+    const size_t lds = (size_t)(tm == 16 ? TileNet<16>::floats(S, amax) : TileNet<32>::floats(S, amax)) * 4;  // the actor's image is the larger
+    const int64_t tiles = (n + tm - 1) / tm;
     const int grid = 2 * (int)((tiles + 3) / 4);
-#define ACT_LAUNCH(C, AM)                                                                       \
+#define ACT_LAUNCH(C, AM, TM)                                                                   \
     {                                                                                           \
         static size_t configured = 0;                                                           \
         if (lds > configured) {                                                                 \
-            const hipError_t e = hipFuncSetAttribute((const void*)act_kernel<C, AM, SAMPLE>,    \
+            const hipError_t e = hipFuncSetAttribute((const void*)act_kernel<C, AM, SAMPLE, TM>, \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                      (int)lds);                                 \
             if (e != hipSuccess) return (int)e;                                                 \
             configured = lds;                                                                   \
         }                                                                                       \
-        act_kernel<C, AM, SAMPLE><<<grid, 256, lds, st>>>(params, S, A, action_var, states, n,  \
-                                                          seed, rng_offset, actions, logprobs,  \
-                                                          values, entropy, states_copy,         \
-                                                          actions_dup);                         \
+        act_kernel<C, AM, SAMPLE, TM><<<grid, 256, lds, st>>>(params, S, A, action_var, states, n, \
+                                                              seed, rng_offset, actions, logprobs, \
+                                                              values, entropy, states_copy,     \
+                                                              actions_dup);                     \
     }
+#define ACT_LAUNCH_TM(C, AM) { if (tm == 16) ACT_LAUNCH(C, AM, 16) else ACT_LAUNCH(C, AM, 32) }
     if (continuous) {
-        if (amax == 4) ACT_LAUNCH(true, 4) else ACT_LAUNCH(true, 8)
+        if (amax == 4) ACT_LAUNCH_TM(true, 4) else ACT_LAUNCH_TM(true, 8)
     } else {
-        if (amax == 4) ACT_LAUNCH(false, 4) else ACT_LAUNCH(false, 8)
+        if (amax == 4) ACT_LAUNCH_TM(false, 4) else ACT_LAUNCH_TM(false, 8)
     }
+#undef ACT_LAUNCH_TM
 #undef ACT_LAUNCH
     return (int)hipGetLastError();
 }

@@ -453,6 +453,36 @@ __device__ __forceinline__ void mlp_fwd_out16(const Net16& L, int S, int A, cons
     }
 }
 
+// ------------------------------------------------------------------ either tile shape behind one name
+// One MLP's LDS image and forward for either tile shape.
+template <int TM> struct TileNet;
+template <> struct TileNet<32> {
+    NetLds L;
+    static __host__ __device__ int floats(int S, int aout) { return (net_lds_floats(S, aout, false) + 3) & ~3; }
+    __device__ void stage(float* base, const float* params, const NetLayout& P, int S, int A, int aout) {
+        L = carve_net_lds(base, S, aout, false);
+        fill_net_lds(L, params, P, S, A, aout, false);
+    }
+    template <int AOUT, class X>
+    __device__ __forceinline__ void forward(int S, int A, const X& x, int lane, float (&o)[AOUT]) const {
+        f32x16 H1[2], H2[2];
+        mlp_fwd_tile_x(L, S, x, lane & 31, lane >> 5, H1, H2);
+        out_layer_act<AOUT>(L, A, H2, lane >> 5, o);
+    }
+};
+template <> struct TileNet<16> {
+    Net16 L;
+    static __host__ __device__ int floats(int S, int aout) { return (net16_lds_floats(S, aout) + 3) & ~3; }
+    __device__ void stage(float* base, const float* params, const NetLayout& P, int S, int A, int aout) {
+        L = carve_net16(base, S, aout);
+        fill_net16(L, params, P, S, A, aout);
+    }
+    template <int AOUT, class X>
+    __device__ __forceinline__ void forward(int S, int A, const X& x, int lane, float (&o)[AOUT]) const {
+        mlp_fwd_out16<AOUT>(L, S, A, x, lane, o);
+    }
+};
+
 // ------------------------------------------------------------------ heads
 // The head functions below switch floating-point contraction off: every multiply and add is
 // rounded as written, so the same (state, action) gives bit-identical log-probs in every kernel

@@ -606,6 +606,27 @@ def test_single_state_session_survives_buffer_growth(eng):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cont,S,A", [(False, 4, 2), (True, 24, 6), (False, 63, 8)])
+def test_act_tile_shapes_agree(eng, cont, S, A):
+    """Small batches run ppo_act / ppo_evaluate on 16-sample tiles (16x16x4 MFMA), large ones on
+    32-sample tiles (32x32x2): the first rows of a large batch equal a small batch of those rows, bit
+    for bit (sampling is keyed by the row index)."""
+    ppo, _ = eng
+    torch.manual_seed(13)
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, cont, 0.5 if cont else None)
+    big, small = 9000, 150
+    x = torch.from_numpy(np.random.default_rng(2).standard_normal((big, S)).astype(np.float32)).cuda()
+    pol = agent.policy_old
+    a_big = pol.act(x, _seed=77, _offset=5)
+    a_small = pol.act(x[:small].contiguous(), _seed=77, _offset=5)
+    for b_, s_ in zip(a_big, a_small):
+        assert torch.equal(b_[:small], s_)
+    e_big = pol.evaluate(x, a_big[0])
+    e_small = pol.evaluate(x[:small].contiguous(), a_big[0][:small].contiguous())
+    for b_, s_ in zip(e_big, e_small):
+        assert torch.equal(b_[:small], s_)
+
+
 def test_batched_update_equals_flat_with_row_end_terminals(eng):
     """N lockstep envs x T steps through the tensor-valued buffer facade == the oracle's flat
     update of the env-major concatenation with every row end flagged terminal."""
