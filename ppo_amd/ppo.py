@@ -463,6 +463,7 @@ class PPO:
         # engine state
         self._rng_seed = None      # drawn from torch's generator on first use (honours torch.manual_seed)
         self._act_session = None   # single-env protocol: session of kernels launched ahead, made on first use
+        self._host_step = None     # ... and its per-step closure
         self._pin = None           # ... or, with PPO_ACT_SESSION=0, the page-locked staging of ppo_act_host
         self.buffer._before_move = self._act_drain
         self.policy_old._before_write = self._act_drain
@@ -517,6 +518,8 @@ class PPO:
         """One env: ``state`` of shape [S] -> int (discrete) or np.ndarray[A] float32 (continuous),
         exactly as the reference.  N lockstep envs: ``state`` of shape [N, S] (ndarray or tensor)
         -> device tensor of N actions (int64 [N] or float32 [N, A]); nothing is copied to the host."""
+        if self._host_step is not None and type(state) is np.ndarray and state.ndim == 1:
+            return self._host_step(state)      # the single-env protocol's steady state
         _require_gpu()
         if not isinstance(state, torch.Tensor) and np.ndim(state) == 1:
             return self._select_action_host(state)
@@ -557,6 +560,8 @@ class PPO:
         (ppo_act_session_step) - no launch and no stream wait between "state known" and "action
         known".  PPO_ACT_SESSION=0: one launch per call with the state in its arguments, and a spin
         on a ticket word the kernel writes next to the action (ppo_act_host)."""
+        if self._host_step is not None:
+            return self._host_step(state)
         if self._pin is None:
             L = _lib.lib()
             # [state (64 words)][action words (8)][ticket word]; page-locked for ppo_act_host's sake
@@ -575,6 +580,12 @@ class PPO:
                 self._act_session = h
                 self._act_step_fn = L.ppo_act_session_step
                 self._act_drain_fn = L.ppo_act_session_drain
+        if self._act_session is not None:
+            if self._rng_seed is None:
+                self._next_rng()
+                self._rng_offset -= 1
+            self._host_step = self._make_session_step()
+            return self._host_step(state)
         self._pin_np[0][:] = state
         b = self.buffer
         lo = b.claim_step(1)
@@ -583,22 +594,50 @@ class PPO:
         cont = self.has_continuous_action_space
         ra = b._row_addr
         (ps, ss), (pa, sa), (pl, sl), (pv, sv) = ra["states"], ra["actions"], ra["logprobs"], ra["state_values"]
-        if self._act_session is not None:
-            rc = self._act_step_fn(
-                self._act_session, pol.flat.data_ptr(), pol._var_host, self._pin_ptr[0], seed, off,
-                ps + lo * ss, pa + lo * sa, pl + lo * sl, pv + lo * sv, self._pin_ptr[1],
-                torch.cuda.current_stream().cuda_stream)
-        else:
-            self._ticket = ticket = (self._ticket % 0x7fffffff) + 1
-            rc = self._act_host(
-                pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var_host,
-                self._pin_ptr[0], ps + lo * ss, seed, off, pa + lo * sa, pl + lo * sl, pv + lo * sv,
-                self._pin_ptr[1], self._pin_ptr[2], ticket, torch.cuda.current_stream().cuda_stream)
+        self._ticket = ticket = (self._ticket % 0x7fffffff) + 1
+        rc = self._act_host(
+            pol.flat.data_ptr(), self.state_dim, self.action_dim, int(cont), pol._var_host,
+            self._pin_ptr[0], ps + lo * ss, seed, off, pa + lo * sa, pl + lo * sl, pv + lo * sv,
+            self._pin_ptr[1], self._pin_ptr[2], ticket, torch.cuda.current_stream().cuda_stream)
         if rc:
             _lib.check(rc)
         if cont:
             return self._pin_np[1].copy()
         return int(self._pin_np[2][0])
+
+    def _make_session_step(self):
+        """The per-step work of the session path as one closure over everything that does not change
+        between steps (this function is most of what a step costs on the host)."""
+        b, cnt, pol = self.buffer, self.buffer._count, self.policy_old
+        state_np, act_np, act_int = self._pin_np
+        state_ptr, act_ptr = self._pin_ptr[0], self._pin_ptr[1]
+        step, sess, seed = self._act_step_fn, self._act_session, self._rng_seed
+        params = pol.flat.data_ptr()           # the flat vector is allocated once
+        cont = self.has_continuous_action_space
+        raw_stream = torch._C._cuda_getCurrentRawStream
+        dev_index = device.index or 0
+
+        def host_step(state):
+            state_np[:] = state
+            lo = cnt["states"]
+            if lo >= b._cap:
+                b.reserve(lo + 1)
+            cnt["states"] = cnt["actions"] = cnt["logprobs"] = cnt["state_values"] = lo + 1
+            self._rng_offset = off = self._rng_offset + 1
+            ra = b._row_addr
+            ps, ss = ra["states"]
+            pa, sa = ra["actions"]
+            pl, sl = ra["logprobs"]
+            pv, sv = ra["state_values"]
+            rc = step(sess, params, pol._var_host, state_ptr, seed, off, ps + lo * ss, pa + lo * sa,
+                      pl + lo * sl, pv + lo * sv, act_ptr, raw_stream(dev_index))
+            if rc:
+                _lib.check(rc)
+            if cont:
+                return act_np.copy()
+            return int(act_int[0])
+
+        return host_step
 
     def act_inplace(self, n_envs):
         """Device-side env variant: the env has already written this step's states into

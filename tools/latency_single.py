@@ -61,3 +61,21 @@ for work_us in (10, 30):
         tot += time.perf_counter() - t0
     print(f"select_action with {work_us} us of host work between calls: {tot / n * 1e6:.1f} us per call")
     agent._act_drain()
+
+# ---- the host wrapper alone: everything select_action does except the library call
+agent = PPO(4, 2, 3e-4, 1e-3, 0.99, 4, 0.2, False, None)
+agent.buffer.reserve(n + 64)
+x = np.random.default_rng(0).standard_normal(4)
+agent.select_action(x)
+agent._act_drain()
+real = agent._act_step_fn
+agent._act_step_fn = lambda *a: 0
+agent._host_step = agent._make_session_step()
+t0 = time.perf_counter()
+for _ in range(n):
+    agent.select_action(x)
+dt_py = (time.perf_counter() - t0) / n
+agent._act_step_fn = real
+agent._host_step = agent._make_session_step()
+agent.buffer.clear()
+print(f"of which the Python wrapper (no library call): {dt_py * 1e6:.1f} us")
