@@ -107,22 +107,8 @@ __device__ __forceinline__ float tanh_head(float x) {
 
 __device__ __forceinline__ f32x16 tanh16_prescaled(f32x16 v) {
     f32x16 o;
-#if !defined(PPO_TANH_ACCURATE) && !defined(PPO_TANH_SCALAR)
-    // the same four operations per element, the add and the fma on register pairs (v_pk_add_f32 /
-    // v_pk_fma_f32: 32 instructions fewer per 32 x 64 activations, +0.4 % on the update kernel)
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        f32x2 e = {__builtin_amdgcn_exp2f(v[r]), __builtin_amdgcn_exp2f(v[r + 1])};
-        e = e + 1.0f;
-        f32x2 q = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-        q = __builtin_elementwise_fma(q, (f32x2){-2.0f, -2.0f}, (f32x2){1.0f, 1.0f});
-        o[r] = q.x;
-        o[r + 1] = q.y;
-    }
-#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = tanh_prescaled(v[r]);
-#endif
     return o;
 }
 
