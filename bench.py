@@ -242,15 +242,29 @@ def main():
         # data-parallel path: host time spent enqueueing the K-epoch loop (launches + collectives)
         phases["dp_host_enqueue_us_per_epoch"] = agent.last_dp_enqueue_s / K * 1e6
 
-    # one instrumented iteration (untimed): events on the launch stream around every fwd/bwd launch
-    # (this selects the per-epoch form of the same launches) and around the scan and normalise launches
-    agent.kernel_events = []
+    # one instrumented iteration (untimed): the library brackets every launch of the K-epoch loop with
+    # events on the launch stream (ppo_kernel_timings; the default product path, as in the timed loop);
+    # the data-parallel path, which has no such loop in C, collects the events itself.  Events around
+    # the scan and normalise launches either way.
+    import ctypes
+    from ppo_amd import _lib, dist as _pdist
+    c_timed = not _pdist.is_distributed()
+    if c_timed:
+        _lib.check(_lib.lib().ppo_kernel_timings_enable(1))
+    else:
+        agent.kernel_events = []
     agent.phase_events = []
     iteration()
     torch.cuda.synchronize()
     events, pev = agent.kernel_events, agent.phase_events
     agent.kernel_events = agent.phase_events = None
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+    if c_timed:
+        tbuf = (ctypes.c_float * 3)()
+        _lib.check(_lib.lib().ppo_kernel_timings(tbuf, 3))
+        _lib.check(_lib.lib().ppo_kernel_timings_enable(0))
+        kern_ms, n_timed = float(tbuf[0]), int(tbuf[2])
+    else:
+        kern_ms, n_timed = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1), len(events)
     phase_ms = {name: a.elapsed_time(b) for name, a, b in pev}
 
     traffic, traffic_source, phase_traffic = None, None, {}
@@ -294,9 +308,10 @@ def main():
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "avg_launch_ms": kern_ms, "launches_timed": len(events),
+                         "avg_launch_ms": kern_ms, "launches_timed": n_timed,
                          "flop_per_sample_epoch": flops_per_sample_epoch(S, A),
-                         "timed_in": "a separate instrumented iteration after the timed loop"},
+                         "timed_in": "a separate instrumented iteration after the timed loop, events on the launch "
+                                     "stream around every launch" + (" (ppo_kernel_timings)" if c_timed else "")},
             "roofline_hbm_phases": hbm,
             "phases": phases,
             "final_loss": float(agent.last_loss[-1].item()),

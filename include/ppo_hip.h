@@ -152,6 +152,16 @@ int ppo_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
                   double lr_critic, double beta1, double beta2, double eps, float* loss_out,
                   void* stream);
 
+/* Kernel timings of the K-epoch loop (no counterpart in the reference; what a profiler would show,
+ * available to the caller without one).  After ppo_kernel_timings_enable(1), every
+ * ppo_update_epochs call (k_epochs <= 256) brackets each of its launches with events on the launch
+ * stream; ppo_kernel_timings waits for the last such call and writes out[0] = mean milliseconds of
+ * the fused forward/backward launch (the replacement of PPO.py:227-244), out[1] = mean milliseconds
+ * of the reduce + Adam launch (PPO.py:245), out[2] = launches of each kind timed (n >= 3).
+ * ppo_kernel_timings_enable(0) switches the events off again. */
+int ppo_kernel_timings_enable(int on);
+int ppo_kernel_timings(float* out, int n);
+
 /* ---- single-env latency path -------------------------------------------------------------------
  * PPO.select_action as the reference's loop calls it (PPO.py:175-198, train.py:176): ONE state on
  * the host in, ONE action on the host out.  host_state: state_dim floats of ordinary host memory

@@ -944,6 +944,54 @@ extern "C" int ppo_reduce_adam_step(int state_dim, int action_dim, const void* w
 
 // The K-epoch loop of PPO.update (PPO.py:224-245) for one process: K x (ppo_epoch_fwdbwd,
 // ppo_reduce_adam_step) enqueued by one call; losses_out[e] receives loss.mean() of epoch e.
+// ---------------------------------------------------------------------------- kernel timings
+// Events on the launch stream around the launches of the K-epoch loop, switched on by
+// ppo_kernel_timings_enable(1).  The events are made on first use and kept (one process drives one
+// device); with timings off ppo_update_epochs does not touch any of this.
+#define PPO_TIMED_EPOCHS_MAX 256
+static struct {
+    int on = 0, epochs = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2 * PPO_TIMED_EPOCHS_MAX + 1] = {};
+    int made = 0;
+} g_timing;
+
+extern "C" int ppo_kernel_timings_enable(int on) {
+    g_timing.on = on != 0;
+    g_timing.epochs = 0;
+    return 0;
+}
+
+static int timing_mark(int i, hipStream_t st) {
+    while (g_timing.made <= i) {
+        const hipError_t e = hipEventCreate(&g_timing.ev[g_timing.made]);
+        if (e != hipSuccess) return (int)e;
+        ++g_timing.made;
+    }
+    return (int)hipEventRecord(g_timing.ev[i], st);
+}
+
+extern "C" int ppo_kernel_timings(float* out, int n) {
+    if (!out || n < 3) return PPO_E_BADARG;
+    out[0] = out[1] = out[2] = 0.f;
+    const int k = g_timing.epochs;
+    if (k == 0) return 0;
+    hipError_t e = hipEventSynchronize(g_timing.ev[2 * k]);
+    if (e != hipSuccess) return (int)e;
+    double fb = 0.0, ra = 0.0;
+    for (int i = 0; i < k; ++i) {
+        float a = 0.f, b = 0.f;
+        if ((e = hipEventElapsedTime(&a, g_timing.ev[2 * i], g_timing.ev[2 * i + 1])) != hipSuccess) return (int)e;
+        if ((e = hipEventElapsedTime(&b, g_timing.ev[2 * i + 1], g_timing.ev[2 * i + 2])) != hipSuccess) return (int)e;
+        fb += a;
+        ra += b;
+    }
+    out[0] = (float)(fb / k);
+    out[1] = (float)(ra / k);
+    out[2] = (float)k;
+    return 0;
+}
+
 extern "C" int ppo_update_epochs(float* params, int state_dim, int action_dim, int continuous,
                                  float action_var, const float* states, const void* actions,
                                  const float* old_logprobs, const float* advantages,
@@ -953,20 +1001,30 @@ extern "C" int ppo_update_epochs(float* params, int state_dim, int action_dim, i
                                  double eps, float* losses_out, void* workspace,
                                  size_t workspace_bytes, void* stream) {
     if (k_epochs < 1 || first_step < 1) return PPO_E_BADARG;
+    const bool timed = g_timing.on && k_epochs <= PPO_TIMED_EPOCHS_MAX;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (timed) {
+        g_timing.epochs = 0;
+        if ((rc = timing_mark(0, st))) return rc;
+    }
     for (int e = 0; e < k_epochs; ++e) {
-        int rc = ppo_epoch_fwdbwd(params, state_dim, action_dim, continuous, action_var, states, actions,
-                                  old_logprobs, advantages, returns_norm, n, n, eps_clip, nullptr,
-                                  nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+        rc = ppo_epoch_fwdbwd(params, state_dim, action_dim, continuous, action_var, states, actions,
+                              old_logprobs, advantages, returns_norm, n, n, eps_clip, nullptr,
+                              nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
         if (rc) return rc;
+        if (timed && (rc = timing_mark(2 * e + 1, st))) return rc;
         rc = ppo_reduce_adam_step(state_dim, action_dim, workspace, workspace_bytes, grad_out, params,
                                   exp_avg, exp_avg_sq, first_step + e, lr_actor, lr_critic, beta1,
                                   beta2, eps, losses_out ? losses_out + e : nullptr, stream);
         if (rc) return rc;
+        if (timed && (rc = timing_mark(2 * e + 2, st))) return rc;
     }
+    if (timed) g_timing.epochs = k_epochs;
     return 0;
 }
 
-extern "C" int ppo_hip_abi_version(void) { return 5; }
+extern "C" int ppo_hip_abi_version(void) { return 6; }
 
 extern "C" const char* ppo_hip_strerror(int code) {
     switch (code) {

@@ -627,6 +627,26 @@ def test_act_tile_shapes_agree(eng, cont, S, A):
         assert torch.equal(b_[:small], s_)
 
 
+def test_kernel_timings_export(eng):
+    """ppo_kernel_timings reports the launches of the K-epoch loop of the default update path, and
+    nothing once switched off."""
+    ppo, _lib = eng
+    L = _lib.lib()
+    torch.manual_seed(1)
+    agent = ppo.PPO(4, 2, 3e-4, 1e-3, 0.99, 5, 0.2, False, None)
+    out = (ctypes.c_float * 3)()
+    for on in (1, 0):
+        _lib.check(L.ppo_kernel_timings_enable(on))
+        agent.synthetic_rollout(64, 16)
+        agent.update()
+        _lib.check(L.ppo_kernel_timings(out, 3))
+        if on:
+            assert int(out[2]) == 5 and 0.0 < out[0] < 50.0 and 0.0 < out[1] < 50.0
+        else:
+            assert int(out[2]) == 0 and out[0] == 0.0
+    assert L.ppo_kernel_timings(out, 2) != 0      # room for fewer than three values: bad argument
+
+
 def test_batched_update_equals_flat_with_row_end_terminals(eng):
     """N lockstep envs x T steps through the tensor-valued buffer facade == the oracle's flat
     update of the env-major concatenation with every row end flagged terminal."""
