@@ -18,14 +18,17 @@
 //  * ppo_act_session_*: the launch itself leaves the critical path.  A kernel is launched BEFORE
 //    its state exists: it loads its weights, then polls a mailbox in page-locked host memory for
 //    the request (bounded: it gives up after about a millisecond, or when told to), serves it, and
-//    exits.  Request numbers are 1 .. 2^31 - 1; the top bit of the mailbox word withdraws the waiter.  Each step posts its request and launches the kernel for the step after, so that launch
+//    exits.  Request numbers are 1 .. 2^31 - 1; the top bit of the mailbox word withdraws the
+//    waiter.  Each step posts its request and launches the kernel for the step after, so that launch
 //    overlaps the device's work on this step.  Every kernel serves at most one request and always
 //    terminates on its own; kernels of one session run on the session's own stream, one after the
 //    other, which is what lets them pass "last request served" through a device word.
 #include "ppo_common.h"
+#include <stddef.h>
 #include <string.h>
 
-struct ActRequest {   // one 64-byte line; seq is written last (host) and read first (device)
+struct ActRequest {   // one 64-byte line; seq is written last (host) and read first (device).  The
+    // kernel reads the line as 16 dwords and reassembles the fields: keep this order and these sizes.
     float* state_row;
     void* action_row;
     float* logprob_row;
@@ -35,6 +38,9 @@ struct ActRequest {   // one 64-byte line; seq is written last (host) and read f
     unsigned seq;
     unsigned pad[2];
 };
+
+static_assert(sizeof(ActRequest) == 64 && offsetof(ActRequest, seed) == 32 && offsetof(ActRequest, action_var) == 48 &&
+              offsetof(ActRequest, seq) == 52, "the kernel reads ActRequest by dword index");
 
 struct ActMailbox {   // page-locked host memory
     ActRequest req;                 // host -> device
@@ -101,12 +107,11 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
             const unsigned served = words[0];
             unsigned g = 0;
             const uint64_t t0 = wall_clock64();
-            for (unsigned it = 0; it < ACT_MAX_POLLS; ++it) {
+            for (unsigned it = 0; it < ACT_MAX_POLLS; ++it) {   // a poll is one read of host memory: about a microsecond
                 const unsigned s = host_load(&mb->req.seq);
                 if (s & ACT_CANCEL_BIT) break;
                 if (s != served) { g = s; break; }
-                if (wall_clock64() - t0 > wait_ticks) break;
-                __builtin_amdgcn_s_sleep(2);
+                if ((it & 7) == 7 && wall_clock64() - t0 > wait_ticks) break;
             }
             go = (int)g;
         }
@@ -120,15 +125,18 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
             }
             return;
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        req.state_row = host_load(&mb->req.state_row);
-        req.action_row = host_load(&mb->req.action_row);
-        req.logprob_row = host_load(&mb->req.logprob_row);
-        req.value_row = host_load(&mb->req.value_row);
-        req.seed = host_load(&mb->req.seed);
-        req.rng_offset = host_load(&mb->req.rng_offset);
-        req.action_var = host_load(&mb->req.action_var);
+        // the request in ONE round trip: lane i takes dword (i & 15) of the request line, lane u < S
+        // its input (loads that go to the host's memory every time; nothing cached to invalidate)
+        const int rw = (int)host_load(reinterpret_cast<const unsigned*>(&mb->req) + (u & 15));
         if (u < S) xv = host_load(&mb->state[u]);
+        auto word = [&](int i) { return (uint64_t)(unsigned)__builtin_amdgcn_readlane(rw, i); };
+        req.state_row = reinterpret_cast<float*>(word(0) | word(1) << 32);
+        req.action_row = reinterpret_cast<void*>(word(2) | word(3) << 32);
+        req.logprob_row = reinterpret_cast<float*>(word(4) | word(5) << 32);
+        req.value_row = reinterpret_cast<float*>(word(6) | word(7) << 32);
+        req.seed = word(8) | word(9) << 32;
+        req.rng_offset = word(10) | word(11) << 32;
+        req.action_var = __uint_as_float((unsigned)word(12));
     } else {
         if (u < S) xv = state->v[u];
     }
