@@ -726,9 +726,10 @@ static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
 
 // Workgroups per role.  The actor's tiles cost more than the critic's (wider output layer, the
 // distribution head, for more than two outputs an extra MFMA weight gradient): measured ratios r
-// of per-tile time are 1.14 (2 discrete actions) and 1.37 (6 continuous).  Every pair of a role
+// of per-tile time are 1.12 (2 discrete actions) and 1.37 (6 continuous).  Every pair of a role
 // runs ceil(tiles / pairs) tiles, so the split minimises max(actor iterations * r, critic
-// iterations); at 524 288 samples that is 138 : 118 (30 and 35 iterations), at 8.4 M samples 148 : 108.
+// iterations); at 524 288 samples that is 135 : 121 (31 and 34 iterations: 273.5 us per launch against
+// 275.8 for 138 : 118 = 30 and 35 iterations, same-box sweep), at 8.4 M samples 148 : 108.
 // The fwd/bwd kernel leaves the split in the workspace header for the reduction kernels.
 #define FB_MAX_ROLE_WGS (3 * FB_GRID / 4)
 #define FB_WS_HEADER 256
@@ -740,7 +741,7 @@ static void role_wgs(int A, int64_t n, int tile, int slots, int& n_actor, int& n
     if (tune && atoi(tune) >= FB_GRID - FB_MAX_ROLE_WGS && atoi(tune) <= FB_MAX_ROLE_WGS) {
         best = atoi(tune);
     } else {
-        const double r = 1.0 + (A > 2 ? 0.062 : 0.072) * A;
+        const double r = 1.0 + (A > 2 ? 0.062 : 0.06) * A;
         double best_cost = 1e300;
         for (int na = FB_GRID - FB_MAX_ROLE_WGS; na <= FB_MAX_ROLE_WGS; ++na) {
             const int64_t ia = (tiles + slots * na - 1) / (slots * na);

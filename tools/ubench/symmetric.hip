@@ -7,6 +7,7 @@
 // build: hipcc -O3 --offload-arch=gfx950 symmetric.hip -o symmetric
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LD 68
@@ -14,7 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float tanh4(float xs) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f), 1.0f); }
 
-template <int WAVES, bool SLIM>
+template <int WAVES, bool SLIM, int LOCK>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const float* __restrict__ x, float* out, unsigned long long* cyc, int n_tiles) {
     extern __shared__ __align__(16) float smem[];
     float* w2f = smem;                 // [64][LD]
@@ -34,8 +35,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const float* __restri
     const float* xrow = x + ((size_t)(blockIdx.x * WAVES + wave) * 32 + c) * 4;
     float xf[3] = {xrow[h], xrow[2 + h], h ? 0.f : 1.f};
     const int c16 = lane & 15, q4 = lane >> 4;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < n_tiles; ++it) {
+        if (LOCK & 8) __syncthreads();
         // ---- layer 1 + tanh
         f32x16 z0 = {0}, z1 = {0};
 #pragma unroll
@@ -46,6 +48,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const float* __restri
         f32x16 H1[2], H2[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { H1[0][r] = tanh4(z0[r]); H1[1][r] = tanh4(z1[r]); }
+        if (LOCK & 1) __syncthreads();
         // ---- layer 2 + tanh
         f32x16 y0 = {0}, y1 = {0};
         {
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const float* __restri
                 *reinterpret_cast<f32x4*>(dzs + c * LD + 4 * h + 32 * t + 8 * q) = dz4;
                 *reinterpret_cast<f32x4*>(h1s + c * LD + 4 * h + 32 * t + 8 * q) = h4;
             }
+        if (LOCK & 2) __syncthreads();
         // ---- dgrad: dH1 = W2^T dZ2 (B operand straight from registers)
         f32x16 d0 = {0}, d1 = {0};
         {
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const float* __restri
             d0[r] *= 1.0f - H1[0][r] * H1[0][r];
             d1[r] *= 1.0f - H1[1][r] * H1[1][r];
         }
+        if (LOCK & 4) __syncthreads();
         // ---- wgrad 2: dW2 += dZ2^T H1 (column reads of the staged rows)
         {
             const float* zcol = dzs + (16 * h) * LD + c;
@@ -162,8 +167,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const float* __restri
                     gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc[4 * s * LD + 16 * t4], xf[s % 3], gW1n[t4], 0, 0, 0);
         }
     }
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    if (lane == 0) cyc[blockIdx.x * WAVES + wave] = t1 - t0;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) { cyc[(blockIdx.x * WAVES + wave) * 2] = t1 - t0; cyc[(blockIdx.x * WAVES + wave) * 2 + 1] = r1 - r0; }
     float s = 0;
     for (int i = 0; i < 16; ++i) s += gW2[0][0][i] + gW2[0][1][i] + gW2[1][0][i] + gW2[1][1][i] + gb2[0][i] + gb2[1][i] + gW3v[0][i] + gW3v[1][i];
     for (int i = 0; i < 8; ++i) s += slim_acc[i];
@@ -171,32 +176,44 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const float* __restri
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int WAVES, bool SLIM>
+template <int WAVES, bool SLIM, int LOCK>
 void run(int n_tiles) {
     float *x, *out; unsigned long long* cyc;
-    (void)hipMalloc(&x, 256 * 8 * 32 * 4 * 4); (void)hipMemset(x, 0, 256 * 8 * 32 * 4 * 4);
-    (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&cyc, 256 * 8 * 8);
+    (void)hipMalloc(&x, 256 * 8 * 32 * 4 * 4); { static float hx[256 * 8 * 32 * 4]; for (int i = 0; i < 256 * 8 * 32 * 4; ++i) hx[i] = (float)rand() / RAND_MAX - 0.5f; (void)hipMemcpy(x, hx, sizeof(hx), hipMemcpyHostToDevice); }
+    (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&cyc, 256 * 8 * 16);
     const size_t lds = ((SLIM ? 1 : 2) * 64 * LD + 8 * 64 + 64 + WAVES * 2 * 32 * LD) * 4;
-    (void)hipFuncSetAttribute((const void*)k<WAVES, SLIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k<WAVES, SLIM, LOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<WAVES, SLIM>), dim3(256), dim3(WAVES * 64), lds, 0, x, out, cyc, n_tiles);
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((k<WAVES, SLIM, LOCK>), dim3(256), dim3(WAVES * 64), lds, 0, x, out, cyc, n_tiles);
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<WAVES, SLIM>), dim3(256), dim3(WAVES * 64), lds, 0, x, out, cyc, n_tiles);
+    hipLaunchKernelGGL((k<WAVES, SLIM, LOCK>), dim3(256), dim3(WAVES * 64), lds, 0, x, out, cyc, n_tiles);
     (void)hipEventRecord(e1, 0);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-    static unsigned long long hc[2048]; (void)hipMemcpy(hc, cyc, 256 * WAVES * 8, hipMemcpyDeviceToHost);
-    double m = 0; for (int i = 0; i < 256 * WAVES; ++i) m += hc[i]; m /= 256 * WAVES;
+    static unsigned long long hc[4096]; (void)hipMemcpy(hc, cyc, 256 * WAVES * 16, hipMemcpyDeviceToHost);
+    // per workgroup the longest wave (the SIMD is busy until its last wave ends), mean over workgroups
+    double m = 0, mean = 0, ghz = 0;
+    for (int b = 0; b < 256; ++b) {
+        unsigned long long mx = 0, rt = 1;
+        for (int w = 0; w < WAVES; ++w) { const unsigned long long v = hc[(b * WAVES + w) * 2]; mean += v; if (v > mx) { mx = v; rt = hc[(b * WAVES + w) * 2 + 1]; } }
+        m += mx; ghz += (double)mx / rt * 0.1;
+    }
+    m /= 256; mean /= 256 * WAVES; ghz /= 256;
     const double per_tile_simd = m / n_tiles / (WAVES / 4);
     // useful MFMA cycles per tile: (6 + 64 + 64 + 64) * 64 + 32 * 32 = 13696
-    printf("%s%d waves per SIMD, LDS %zu B: %8.0f cycles per tile per wave, %8.0f cycles per tile per SIMD; MFMA share %.3f; launch %.3f ms (%.2f GHz)\n",
-           SLIM ? "(slim: W2^T aliased, b2/W3 sums in 8 registers) " : "", WAVES / 4, lds, m / n_tiles, per_tile_simd, 13696.0 / per_tile_simd, ms, m / (ms * 1e6));
+    printf("lock %d: %s%d waves per SIMD, LDS %zu B: %8.0f cycles per tile per wave, %8.0f cycles per tile per SIMD; MFMA share %.3f; launch %.3f ms = %.2f us per tile and SIMD; in-kernel clock %.2f GHz; mean wave / longest wave %.3f\n",
+           LOCK, SLIM ? "(slim) " : "", WAVES / 4, lds, m / n_tiles, per_tile_simd, 13696.0 / per_tile_simd, ms, ms * 1e3 / n_tiles / (WAVES / 4), ghz, mean / m);
     (void)hipFree(x); (void)hipFree(out); (void)hipFree(cyc);
 }
 
 int main() {
-    run<4, false>(200);
-    run<4, true>(200);
-    run<8, true>(200);
+    run<4, true, 0>(36);
+    run<8, true, 0>(18);
+    run<8, true, 1>(18);
+    run<8, true, 2>(18);
+    run<8, true, 3>(18);
+    run<8, true, 7>(18);
+    run<8, true, 15>(18);
+    run<8, true, 10>(18);
     return 0;
 }
