@@ -120,61 +120,25 @@ def cpu_baseline(cfg, threads):
 
 _watchdog_file = None
 
+# the other BASELINE.json configurations, measured after the headline one by the default single-GPU run
+# (a few iterations each) and reported under "other_configs" of the same JSON line
+OTHER_CONFIGS = (("c5", 2, 1), ("c1", 3, 1), ("c3", 3, 1))   # (config, steps, warmup)
 
-def main():
-    global _watchdog_file
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
-    ap.add_argument("--k-epochs", type=int, default=None)
-    ap.add_argument("--n-envs", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16)
-    args = ap.parse_args()
-    cfg = dict(CONFIGS[args.config])
-    if args.k_epochs:
-        cfg["K"] = args.k_epochs
-    if args.n_envs:
-        cfg["n_envs"] = args.n_envs
-    cfg["name"] = cfg["name"].format(**cfg)
-    flat = cfg["n_envs"] == 1
 
+def measure(config_key, cfg, steps, warmup, world, rank, custom_shape, with_cpu, cpu_threads):
+    """One configuration: `warmup` untimed + `steps` timed iterations of the default product path between
+    barriers (max over ranks), then one iteration with a host sync between the phases and one
+    instrumented iteration for the kernel times.  Returns the fields of the JSON line (rank 0: all of
+    them; other ranks: None)."""
+    import contextlib
+    import ctypes
+    import io
     import numpy as np
     import torch
     import torch.distributed as td
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if os.environ.get("PPO_BENCH_WATCHDOG"):     # rehearsal aid: dump the Python stacks of a stuck rank
-        import faulthandler
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        # the file object has to stay alive: faulthandler only holds its descriptor
-        _watchdog_file = open(os.path.join(ROOT, "gpurun_out", f"watchdog_rank{rank}.txt"), "w")
-        faulthandler.dump_traceback_later(int(os.environ["PPO_BENCH_WATCHDOG"]), exit=True, file=_watchdog_file)
-    grouped = world > 1
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # one rank per GPU over RCCL; PPO_BENCH_BACKEND=gloo lets several ranks share one GPU to
-        # rehearse the distributed code path on a single-GPU box (not a measurement)
-        backend = os.environ.get("PPO_BENCH_BACKEND", "nccl")
-        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-        os.environ["LOCAL_RANK"] = str(local)
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            td.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            td.init_process_group(backend)
-    elif os.environ.get("PPO_BENCH_FORCE_GROUP") == "1":
-        # rehearsal: a one-rank RCCL group; with PPO_DIST_FORCE=1 the update takes the data-parallel path
-        torch.cuda.set_device(0)
-        td.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
-                              device_id=torch.device("cuda", 0))
-        grouped = True
-    import contextlib
-    import io
     with contextlib.redirect_stdout(io.StringIO()):
-        from ppo_amd import ppo
+        from ppo_amd import _lib, dist as _pdist, ppo
+    flat = cfg["n_envs"] == 1
     S, A, N, T, K = cfg["S"], cfg["A"], cfg["n_envs"], cfg["horizon"], cfg["K"]
     torch.manual_seed(0)                       # identical initial weights on every rank
     agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, K, 0.2, cfg["continuous"], cfg["std"])
@@ -217,16 +181,17 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         iteration()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         iteration()
     barrier()
     dt = time.perf_counter() - t0
+    on_device = world > 1 and td.get_backend() == "nccl"
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_device else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -244,85 +209,192 @@ def main():
 
     # one instrumented iteration (untimed): the library brackets every launch of the K-epoch loop with
     # events on the launch stream (ppo_kernel_timings; the default product path, as in the timed loop);
-    # the data-parallel path, which has no such loop in C, collects the events itself.  Events around
-    # the scan and normalise launches either way.
-    import ctypes
-    from ppo_amd import _lib, dist as _pdist
+    # the data-parallel path, which has no such loop in C, collects the events itself (and events around
+    # every gradient all-reduce).  Events around the scan and normalise launches either way.
     c_timed = not _pdist.is_distributed()
     if c_timed:
         _lib.check(_lib.lib().ppo_kernel_timings_enable(1))
     else:
         agent.kernel_events = []
+        agent.comm_events = []
     agent.phase_events = []
     iteration()
     torch.cuda.synchronize()
-    events, pev = agent.kernel_events, agent.phase_events
-    agent.kernel_events = agent.phase_events = None
+    events, pev, cev = agent.kernel_events, agent.phase_events, agent.comm_events
+    agent.kernel_events = agent.phase_events = agent.comm_events = None
+    reduce_adam_ms = None
     if c_timed:
         tbuf = (ctypes.c_float * 3)()
         _lib.check(_lib.lib().ppo_kernel_timings(tbuf, 3))
         _lib.check(_lib.lib().ppo_kernel_timings_enable(0))
-        kern_ms, n_timed = float(tbuf[0]), int(tbuf[2])
+        kern_ms, reduce_adam_ms, n_timed = float(tbuf[0]), float(tbuf[1]), int(tbuf[2])
     else:
         kern_ms, n_timed = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1), len(events)
     phase_ms = {name: a.elapsed_time(b) for name, a, b in pev}
+    # the per-epoch cost next to the dominant kernel (reduction + Adam launch, kernel boundaries)
+    phases["update_minus_fwdbwd_ms"] = phases["update_ms"] - K * kern_ms
+    if reduce_adam_ms is not None:
+        phases["reduce_adam_us_per_epoch"] = reduce_adam_ms * 1e3
+
+    # what the first multi-rank run saw: backend, ranks, and whether the replicas agree bit for bit
+    dist_info = None
+    if world > 1:
+        flatp = agent.policy.flat.double()
+        mine = torch.stack([flatp.sum(), flatp.abs().sum(), agent.last_loss[-1].double(),
+                            agent.policy_old.flat.double().sum()])
+        mine = mine if on_device else mine.cpu()
+        hi, lo = mine.clone(), mine.clone()
+        td.all_reduce(hi, op=td.ReduceOp.MAX)
+        td.all_reduce(lo, op=td.ReduceOp.MIN)
+        spread = (hi - lo).cpu().tolist()
+        dist_info = {"backend": td.get_backend(), "world_size": td.get_world_size(),
+                     "replica_check": {"param_sum_spread": spread[0], "param_abs_sum_spread": spread[1],
+                                       "last_loss_spread": spread[2], "policy_old_sum_spread": spread[3],
+                                       "replicas_identical": all(v == 0.0 for v in spread)},
+                     "allreduce_us_per_epoch": (sum(a.elapsed_time(b) for a, b in cev) / max(len(cev), 1) * 1e3
+                                                if cev else None),
+                     "allreduce_bytes": int(agent.optimizer.grad.numel() * 4),
+                     "dp_host_enqueue_us_per_epoch": phases.get("dp_host_enqueue_us_per_epoch")}
 
     traffic, traffic_source, phase_traffic = None, None, {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        rec = pmc.get(args.config, {})
-        if not (args.n_envs or args.k_epochs):
-            phase_traffic = pmc.get("hbm_phases_" + args.config, {})
-        if rec and not (args.n_envs or args.k_epochs):   # measured for the default shape only
+        rec = pmc.get(config_key, {})
+        if not custom_shape:
+            phase_traffic = pmc.get("hbm_phases_" + config_key, {})
+        if rec and not custom_shape:   # measured for the default shape only
             traffic = rec.get("bytes_per_launch")
             traffic_source = f"{rec.get('source')} (rocprofv3 --pmc passes of this workload, not measured by this run)"
     except OSError:
         pass
-    if rank == 0:
-        n = N * T
-        steps_total = n * world * args.steps
-        flops_launch = flops_per_sample_epoch(S, A) * n
-        achieved = flops_launch / (kern_ms * 1e-3) / 1e12
-        hbm = []
-        for name, kernel, pmc_key, bps in (("scan", "scan_flat_reduce/carries/apply + moments_finalize" if flat else
-                                            "scan_rows_kernel + moments_finalize", "scan_rows_kernel",
-                                            SCAN_BYTES_PER_STEP),
-                                           ("normalize", "normalize_adv_kernel", "normalize_adv_kernel",
-                                            NORMALIZE_BYTES_PER_STEP)):
-            if name in phase_ms:
-                gbs = bps * n / (phase_ms[name] * 1e-3) / 1e9
-                hbm.append({"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": gbs / PEAK_HBM_GBS,
-                            "traffic": phase_traffic.get(pmc_key, {}).get("bytes_per_launch"),
-                            "avg_launch_ms": phase_ms[name], "bytes_per_step": bps})
-        out = {
-            "metric": "env-steps/sec (act+return scan+K-epoch update)",
-            "value": steps_total / dt, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": cfg["name"], "n_envs_per_gpu": N, "horizon": T, "K_epochs": K,
-                       "state_dim": S, "action_dim": A, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "fwdbwd_kernel", "achieved": achieved,
-                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "avg_launch_ms": kern_ms, "launches_timed": n_timed,
-                         "flop_per_sample_epoch": flops_per_sample_epoch(S, A),
-                         "timed_in": "a separate instrumented iteration after the timed loop, events on the launch "
-                                     "stream around every launch" + (" (ppo_kernel_timings)" if c_timed else "")},
-            "roofline_hbm_phases": hbm,
-            "phases": phases,
-            "final_loss": float(agent.last_loss[-1].item()),
-        }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only: other ranks must not wait for it
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
-        print(json.dumps(out), flush=True)
+    final_loss = float(agent.last_loss[-1].item())
+    agent.close()
+    del agent
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    n = N * T
+    steps_total = n * world * steps
+    flops_launch = flops_per_sample_epoch(S, A) * n
+    achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+    hbm = []
+    for name, kernel, pmc_key, bps in (("scan", "scan_flat_reduce/carries/apply + moments_finalize" if flat else
+                                        "scan_rows_kernel + moments_finalize", "scan_rows_kernel",
+                                        SCAN_BYTES_PER_STEP),
+                                       ("normalize", "normalize_adv_kernel", "normalize_adv_kernel",
+                                        NORMALIZE_BYTES_PER_STEP)):
+        if name in phase_ms:
+            gbs = bps * n / (phase_ms[name] * 1e-3) / 1e9
+            hbm.append({"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": gbs / PEAK_HBM_GBS,
+                        "traffic": phase_traffic.get(pmc_key, {}).get("bytes_per_launch"),
+                        "avg_launch_ms": phase_ms[name], "bytes_per_step": bps})
+    out = {
+        "metric": "env-steps/sec (act+return scan+K-epoch update)",
+        "value": steps_total / dt, "unit": "env-steps/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": cfg["name"], "n_envs_per_gpu": N, "horizon": T, "K_epochs": K,
+                   "state_dim": S, "action_dim": A, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "fwdbwd_kernel", "achieved": achieved,
+                     "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                     "traffic_source": traffic_source,
+                     "avg_launch_ms": kern_ms, "launches_timed": n_timed,
+                     "flop_per_sample_epoch": flops_per_sample_epoch(S, A),
+                     "timed_in": "a separate instrumented iteration after the timed loop, events on the launch "
+                                 "stream around every launch" + (" (ppo_kernel_timings)" if c_timed else "")},
+        "roofline_hbm_phases": hbm,
+        "phases": phases,
+        "final_loss": final_loss,
+    }
+    if dist_info is not None:
+        out["distributed"] = dist_info
+    if with_cpu and world == 1:
+        out["cpu_baseline"] = cpu_baseline(cfg, cpu_threads)
+    return out
+
+
+def main():
+    global _watchdog_file
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--k-epochs", type=int, default=None)
+    ap.add_argument("--n-envs", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of the other BASELINE.json configurations after the headline one")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.k_epochs:
+        cfg["K"] = args.k_epochs
+    if args.n_envs:
+        cfg["n_envs"] = args.n_envs
+    cfg["name"] = cfg["name"].format(**cfg)
+    custom_shape = bool(args.n_envs or args.k_epochs)
+
+    import torch
+    import torch.distributed as td
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("PPO_BENCH_WATCHDOG"):     # rehearsal aid: dump the Python stacks of a stuck rank
+        import faulthandler
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        # the file object has to stay alive: faulthandler only holds its descriptor
+        _watchdog_file = open(os.path.join(ROOT, "gpurun_out", f"watchdog_rank{rank}.txt"), "w")
+        faulthandler.dump_traceback_later(int(os.environ["PPO_BENCH_WATCHDOG"]), exit=True, file=_watchdog_file)
+    grouped = world > 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank per GPU over RCCL; PPO_BENCH_BACKEND=gloo lets several ranks share one GPU to
+        # rehearse the distributed code path on a single-GPU box (not a measurement)
+        backend = os.environ.get("PPO_BENCH_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        os.environ["LOCAL_RANK"] = str(local)
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend)
+    elif os.environ.get("PPO_BENCH_FORCE_GROUP") == "1":
+        # rehearsal: a one-rank RCCL group; with PPO_DIST_FORCE=1 the update takes the data-parallel path
+        torch.cuda.set_device(0)
+        td.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                              device_id=torch.device("cuda", 0))
+        grouped = True
+
+    # the CPU leg of a multi-rank run is timed by rank 0 after the group is gone, so that no rank waits
+    # for it inside a collective
+    out = measure(args.config, cfg, args.steps, args.warmup, world, rank, custom_shape,
+                  with_cpu=not args.no_cpu_baseline and world == 1, cpu_threads=args.cpu_threads)
+    if world == 1 and not grouped and args.config == "c4" and not custom_shape and not args.no_other_configs:
+        others = {}
+        for key, steps, warmup in OTHER_CONFIGS:
+            c = dict(CONFIGS[key])
+            c["name"] = c["name"].format(**c)
+            o = measure(key, c, steps, warmup, 1, 0, False, with_cpu=not args.no_cpu_baseline,
+                        cpu_threads=args.cpu_threads)
+            others[key] = {"workload": c["name"], "value": o["value"], "unit": o["unit"], "steps": steps,
+                           "warmup": warmup, "ms_per_step": o["ms_per_step"],
+                           "roofline_frac": o["roofline"]["frac"],
+                           "fwdbwd_avg_launch_ms": o["roofline"]["avg_launch_ms"], "phases": o["phases"],
+                           "cpu_baseline_value": o.get("cpu_baseline", {}).get("value"),
+                           "cpu_baseline_sample": o.get("cpu_baseline", {}).get("sample")}
+        out["other_configs"] = others
     if grouped:
         if world > 1:
             td.barrier()
         td.destroy_process_group()
+    if rank == 0:
+        if world > 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -191,13 +191,17 @@ int ppo_act_host(const float* params, int state_dim, int action_dim, int continu
  * kernel after _create / _drain is ordered behind the work already enqueued on after_stream.
  * _drain withdraws the waiting kernel and waits for the session's stream: call it before the
  * weights behind `params` change, before the rows' storage moves, and before exit (_destroy does).
+ * The waiting kernel loads its weights when it is launched, one step early: params_version is the
+ * caller's count of writes to the vector behind `params` (any number that changes whenever the
+ * contents do); a step whose params or params_version differ from those the waiting kernel was
+ * launched under withdraws that kernel and is served by one launched now.
  * One session serves one caller thread.  No counterpart in the reference: PPO.py:175-198 pays a
  * full launch per step. */
 typedef struct ppo_act_session ppo_act_session;
 int ppo_act_session_create(ppo_act_session** out, int state_dim, int action_dim, int continuous,
                            int wait_us);
-int ppo_act_session_step(ppo_act_session* session, const float* params, float action_var,
-                         const float* host_state, uint64_t seed, uint64_t rng_offset, float* state_row,
+int ppo_act_session_step(ppo_act_session* session, const float* params, uint64_t params_version,
+                         float action_var, const float* host_state, uint64_t seed, uint64_t rng_offset, float* state_row,
                          void* action_row, float* logprob_row, float* value_row, void* action_out,
                          void* after_stream);
 int ppo_act_session_drain(ppo_act_session* session);
@@ -212,10 +216,12 @@ int ppo_synth_env_step(float* states_out, float* rewards_out, uint8_t* terminals
                        int64_t n_envs, int state_dim, int reward_kind, float p_terminal,
                        int64_t step, int64_t horizon, uint64_t seed, void* stream);
 
-/* A whole lockstep rollout of the synthetic envs: for t in [0, n_steps) one ppo_synth_env_step
- * into rows [t*n_envs, (t+1)*n_envs) of the time-major buffers, then one ppo_act on those rows
- * (rng_offset = act_offset0 + t).  Exactly the launches the per-step calls make, enqueued from C.
- * Stands in for the loop of train.py:173-181 in the measurement harness. */
+/* A whole lockstep rollout of the synthetic envs in ONE launch: a persistent kernel in which a
+ * workgroup owns a tile of envs for all n_steps steps (one wave the actor, one the critic, one the
+ * env's draws).  The buffers it leaves are bit-identical to n_steps rounds of ppo_synth_env_step into
+ * rows [t*n_envs, (t+1)*n_envs) of the time-major buffers followed by ppo_act on those rows
+ * (rng_offset = act_offset0 + t).  Stands in for the loop of train.py:173-181 in the measurement
+ * harness. */
 int ppo_synth_rollout(const float* params, int state_dim, int action_dim, int continuous,
                       float action_var, int64_t n_envs, int64_t n_steps, int reward_kind,
                       float p_terminal, int64_t step0, int64_t horizon, uint64_t env_seed,

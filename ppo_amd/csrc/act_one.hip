@@ -286,6 +286,7 @@ struct ppo_act_session {
     hipEvent_t after;         // orders the first kernel after a drain behind the caller's stream
     int S, A, continuous;
     const float* params;      // weights the waiting kernels were launched with
+    uint64_t version;         // ... and the caller's version number of their contents
     unsigned seq;             // last request posted
     unsigned seen_unserved;
     int inflight;             // kernels launched and not yet known to have ended
@@ -309,15 +310,20 @@ extern "C" int ppo_act_session_create(ppo_act_session** out, int state_dim, int 
     ppo_act_session* s = new ppo_act_session();
     s->S = state_dim; s->A = action_dim; s->continuous = continuous;
     s->wait_ticks = (unsigned)wait_us * 100u;   // wall_clock64 counts at 100 MHz
-    hipError_t e = hipHostMalloc((void**)&s->mb, sizeof(ActMailbox), hipHostMallocDefault);
+    // The protocol needs fine-grained coherent host memory (the device's system-scope loads must see the
+    // host's stores and the host the ticket): asked for explicitly, whatever HIP_HOST_COHERENT says.
+    hipError_t e = hipHostMalloc((void**)&s->mb, sizeof(ActMailbox), hipHostMallocCoherent);
     if (e == hipSuccess) e = hipMalloc((void**)&s->words, 2 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(s->words, 0, 2 * sizeof(unsigned));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->after, hipEventDisableTiming);
+    // cleared on the session's own (non-blocking) stream, ahead of its first kernel
+    if (e == hipSuccess) e = hipMemsetAsync(s->words, 0, 2 * sizeof(unsigned), s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) {
         if (s->mb) (void)hipHostFree(s->mb);
         if (s->words) (void)hipFree(s->words);
         if (s->stream) (void)hipStreamDestroy(s->stream);
+        if (s->after) (void)hipEventDestroy(s->after);
         delete s;
         return (int)e;
     }
@@ -348,19 +354,25 @@ extern "C" int ppo_act_session_destroy(ppo_act_session* s) {
     return rc;
 }
 
-extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, float action_var,
+extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, uint64_t params_version,
+                                    float action_var,
                                     const float* host_state, uint64_t seed, uint64_t rng_offset,
                                     float* state_row, void* action_row, float* logprob_row,
                                     float* value_row, void* action_out, void* after_stream) {
     if (!s || !params || !host_state || !state_row || !action_row || !logprob_row || !value_row || !action_out)
         return PPO_E_BADARG;
-    if (s->params != params || s->seq >= 0x7ffffff0u) {   // other weights (or the counter is used up): start over
+    // The kernel that waits for this request was launched a step ago and loaded its weight rows then.
+    // Other weights - another vector, or the same vector written since (the caller's version number
+    // moved) - or a used-up counter: withdraw it and start over with a kernel launched now.
+    if (s->params != params || s->version != params_version || s->seq >= 0x7ffffff0u) {
         const int rc = ppo_act_session_drain(s);
         if (rc) return rc;
         s->params = params;
+        s->version = params_version;
         if (s->seq >= 0x7ffffff0u) {
             s->seq = 0;
-            const hipError_t e = hipMemset(s->words, 0, sizeof(unsigned));
+            hipError_t e = hipMemsetAsync(s->words, 0, sizeof(unsigned), s->stream);   // the drained stream is idle
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
             if (e != hipSuccess) return (int)e;
         }
     }

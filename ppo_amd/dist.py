@@ -42,12 +42,13 @@ def merge_moments_list(triples):
 
 
 def _stage_through_host(t):
-    """gloo (the CPU backend the tests and single-GPU rehearsals use) gets host tensors: its
-    collectives on device tensors stage through the host anyway, and with two ranks sharing one GPU
-    its all_reduce on a device tensor was seen never to complete (both ranks inside the same
-    all_reduce; stacks in profiles/r02_dp_rehearsal.txt).  RCCL ("nccl") works on the device tensors
-    directly.  PPO_DIST_GLOO_DEVICE=1 switches the staging off to reproduce that stall."""
-    return t.is_cuda and td.get_backend() == "gloo" and os.environ.get("PPO_DIST_GLOO_DEVICE") != "1"
+    """gloo (the CPU backend the tests and single-GPU rehearsals use) gets host tensors.  Its
+    collectives on device tensors stage through the host anyway, on a side stream ordered behind the
+    caller's stream by an event; with two ranks time-slicing one GPU that wait was seen not to end
+    when the work in front of it was the fused fwd/bwd kernel (it always ends after a host
+    synchronize, and behind ordinary kernels: profiles/r03_gloo_probe.txt).  The blocking copy here
+    is that host synchronize.  RCCL ("nccl", one process per GPU) works on the device tensors."""
+    return t.is_cuda and td.get_backend() == "gloo"
 
 
 def merge_moments(moments):

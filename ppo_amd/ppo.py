@@ -11,9 +11,11 @@ Beyond the reference surface (which handles one env step per call) the same obje
 batch of N lockstep envs per call: ``select_action(states[N, S])`` and tensor-valued
 ``buffer.rewards.append(r[N])`` / ``buffer.is_terminals.append(done[N])``.
 """
+import atexit
 import ctypes
 import os
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -37,6 +39,15 @@ else:
 print("============================================================================================")
 
 HIDDEN = 64
+
+
+def _close_at_exit(agent_ref):
+    agent = agent_ref()
+    if agent is not None:
+        try:
+            agent.close()
+        except Exception:
+            pass
 
 
 def _require_gpu():
@@ -160,8 +171,9 @@ class RolloutBuffer:
     def reserve(self, rows):
         if rows <= self._cap:
             return
-        if self._before_move is not None:
-            self._before_move()   # kernels that still write rows of the old storage finish first
+        hook = self._before_move() if self._before_move is not None else None   # (a weakref.WeakMethod)
+        if hook is not None:
+            hook()   # kernels that still write rows of the old storage finish first
         cap = max(rows, 2 * self._cap, 1024)
         for name, (shp, dt) in self._shapes().items():
             new = torch.empty((cap,) + shp, dtype=dt, device=self._dev)
@@ -294,8 +306,11 @@ class ActorCritic(nn.Module):
             n = p.numel()
             view = flat[off:off + n].view(shp)
             view.copy_(p.data)
-            p.data = view
-            p.requires_grad_(False)
+            # a Parameter made FROM the view shares the flat vector's version counter (one assigned
+            # through .data would not): an in-place write through any of the 12 tensors moves
+            # flat._version, which the single-state session checks before every step
+            mod_path, attr = key.rsplit(".", 1)
+            setattr(self.get_submodule(mod_path), attr, nn.Parameter(view, requires_grad=False))
             off += n
         assert off == total
         self.flat = flat
@@ -303,8 +318,9 @@ class ActorCritic(nn.Module):
     _before_write = None   # called before load_state_dict overwrites the parameters
 
     def load_state_dict(self, *args, **kwargs):
-        if self._before_write is not None:
-            self._before_write()
+        hook = self._before_write() if self._before_write is not None else None   # (a weakref.WeakMethod)
+        if hook is not None:
+            hook()
         return super().load_state_dict(*args, **kwargs)
 
     def _apply(self, fn, recurse=True):
@@ -465,13 +481,16 @@ class PPO:
         self._act_session = None   # single-env protocol: session of kernels launched ahead, made on first use
         self._host_step = None     # ... and its per-step closure
         self._pin = None           # ... or, with PPO_ACT_SESSION=0, the page-locked staging of ppo_act_host
-        self.buffer._before_move = self._act_drain
-        self.policy_old._before_write = self._act_drain
+        # weak: the hooks must not keep this object alive (a cycle would leave the session to the cycle
+        # collector, i.e. possibly to interpreter shutdown, after the HIP runtime is gone)
+        self.buffer._before_move = weakref.WeakMethod(self._act_drain)
+        self.policy_old._before_write = weakref.WeakMethod(self._act_drain)
         self._rng_offset = 0
         self._ws = None
         self._moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.kernel_events = None  # set to a list to collect (start, end) CUDA events around every fwd/bwd launch
         self.phase_events = None   # set to a list to collect (name, start, end) events around scan / normalise
+        self.comm_events = None    # set to a list to collect (start, end) events around every gradient all-reduce
         self.last_dp_enqueue_s = None  # data-parallel path: host seconds spent enqueueing the last K-epoch loop
         self.last_loss = None      # device tensor [K_epochs]: loss.mean() of every epoch of the last update
         self.debug_outputs = None  # optional dict of per-sample first-epoch outputs (set by update(debug=True))
@@ -546,11 +565,20 @@ class PPO:
         if self._act_session is not None:
             _lib.check(self._act_drain_fn(self._act_session))
 
+    def close(self):
+        """Ends the single-state session (withdraws the kernel that waits for the next state, waits for
+        the session's stream, frees its mailbox and stream).  Safe to call more than once; the next
+        single-state select_action opens a new session.  Called at interpreter exit for every live
+        agent, before the HIP runtime goes away."""
+        sess, self._act_session = getattr(self, "_act_session", None), None
+        self._host_step = None
+        self._pin = None
+        if sess is not None:
+            _lib.check(_lib.lib().ppo_act_session_destroy(sess))
+
     def __del__(self):
         try:
-            if self._act_session is not None:
-                _lib.lib().ppo_act_session_destroy(self._act_session)
-                self._act_session = None
+            self.close()
         except Exception:
             pass
 
@@ -560,6 +588,10 @@ class PPO:
         (ppo_act_session_step) - no launch and no stream wait between "state known" and "action
         known".  PPO_ACT_SESSION=0: one launch per call with the state in its arguments, and a spin
         on a ticket word the kernel writes next to the action (ppo_act_host)."""
+        if type(state) is not np.ndarray:
+            state = np.asarray(state)
+        if state.shape != (self.state_dim,):
+            raise ValueError(f"select_action: state of shape {state.shape}, expected {(self.state_dim,)}")
         if self._host_step is not None:
             return self._host_step(state)
         if self._pin is None:
@@ -578,6 +610,7 @@ class PPO:
                                                     int(self.has_continuous_action_space),
                                                     int(os.environ.get("PPO_ACT_WAIT_US", "1000"))))
                 self._act_session = h
+                atexit.register(_close_at_exit, weakref.ref(self))
                 self._act_step_fn = L.ppo_act_session_step
                 self._act_drain_fn = L.ppo_act_session_drain
         if self._act_session is not None:
@@ -612,12 +645,16 @@ class PPO:
         state_np, act_np, act_int = self._pin_np
         state_ptr, act_ptr = self._pin_ptr[0], self._pin_ptr[1]
         step, sess, seed = self._act_step_fn, self._act_session, self._rng_seed
-        params = pol.flat.data_ptr()           # the flat vector is allocated once
+        flat = pol.flat
+        params = flat.data_ptr()               # the flat vector is allocated once
+        want_shape = (self.state_dim,)
         cont = self.has_continuous_action_space
         raw_stream = torch._C._cuda_getCurrentRawStream
         dev_index = device.index or 0
 
         def host_step(state):
+            if state.shape != want_shape:
+                raise ValueError(f"select_action: state of shape {state.shape}, expected {want_shape}")
             state_np[:] = state
             lo = cnt["states"]
             if lo >= b._cap:
@@ -629,7 +666,9 @@ class PPO:
             pa, sa = ra["actions"]
             pl, sl = ra["logprobs"]
             pv, sv = ra["state_values"]
-            rc = step(sess, params, pol._var_host, state_ptr, seed, off, ps + lo * ss, pa + lo * sa,
+            # flat._version counts the in-place writes to the weights (through any of their views): a
+            # write since the waiting kernel was launched makes the library replace that kernel
+            rc = step(sess, params, flat._version, pol._var_host, state_ptr, seed, off, ps + lo * ss, pa + lo * sa,
                       pl + lo * sl, pv + lo * sv, act_ptr, raw_stream(dev_index))
             if rc:
                 _lib.check(rc)
@@ -818,7 +857,14 @@ class PPO:
                 continue
             _lib.check(L.ppo_grad_reduce(self.state_dim, self.action_dim, ws.data_ptr(), ws.numel(),
                                          opt.grad.data_ptr(), st))
+            if self.comm_events is not None:
+                cev0 = torch.cuda.Event(enable_timing=True)
+                cev0.record()
             _dist.all_reduce_sum(opt.grad)
+            if self.comm_events is not None:
+                cev1 = torch.cuda.Event(enable_timing=True)
+                cev1.record()
+                self.comm_events.append((cev0, cev1))
             if debug and e == 0:
                 dbg["grad"] = opt.grad[:P].clone()
                 dbg["returns_norm"] = returns.clone()

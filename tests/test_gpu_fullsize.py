@@ -130,6 +130,72 @@ def test_full_size_iteration_equals_its_per_step_form(eng):
     assert torch.isfinite(res[0][1]).all()
 
 
+def test_c5_full_size_rollout_and_update(eng):
+    """The large configuration at its real size: 65 536 envs x 128 steps of a HalfCheetah-shaped
+    continuous policy (8 388 608 samples, observations 26 wide: 872 MB of states).  One fused rollout and
+    one update epoch: finite and bit-reproducible; the first epoch re-evaluates the rollout's log-probs
+    to rounding; the full gradient is the sum of two uneven shards' gradients; and on a 262 144-sample
+    slice the gradient equals the CPU restatement's."""
+    ppo, _lib = eng
+    L = _lib.lib()
+    S, A, N, T = 26, 6, 65536, 128
+    n = N * T
+    res = []
+    keep = None
+    for rep in range(2):
+        torch.manual_seed(0)
+        agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 1, 0.2, True, 0.6)
+        agent.buffer.reserve(n)
+        agent.synthetic_rollout(N, T, 1, -1.0, step0=0, env_seed=1234)
+        b = agent.buffer
+        if rep == 0:
+            flat0 = agent.policy.flat.clone()
+            keep = [b.rows(k, 0, n).clone() for k in ("states", "actions", "logprobs")]
+        agent.update(debug=(rep == 0))
+        torch.cuda.synchronize()
+        res.append((agent.policy.flat.clone(), agent.last_loss.clone()))
+        if rep == 0:
+            dbg = agent.debug_outputs
+        del agent
+    assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])    # bit-reproducible
+    assert not torch.equal(res[0][0], flat0)                                           # and it did step
+    xs, acts, old = keep
+    # the update kernel re-evaluates the rollout's log-probs (its output layer sums in another order
+    # than act's, so to rounding, not to the bit): ratios of the first epoch are 1 within 1e-5
+    assert (dbg["logprobs"] - old).abs().max().item() < 1e-5
+    adv, ret, g_full = dbg["advantages"], dbg["returns_norm"], dbg["grad"]
+    assert torch.isfinite(adv).all() and torch.isfinite(ret).all() and torch.isfinite(g_full).all()
+    var = float(np.float32(0.6 * 0.6))
+    ws = torch.empty(L.ppo_workspace_bytes(S, A, n), dtype=torch.uint8, device="cuda")
+
+    def grad_of(lo, hi, n_global):
+        g = torch.empty(flat0.numel() + 2, dtype=torch.float32, device="cuda")
+        _lib.check(L.ppo_epoch_fwdbwd(flat0.data_ptr(), S, A, 1, var, xs[lo:hi].data_ptr(), acts[lo:hi].data_ptr(),
+                                      old[lo:hi].data_ptr(), adv[lo:hi].data_ptr(), ret[lo:hi].data_ptr(),
+                                      hi - lo, n_global, 0.2, None, None, None, None, ws.data_ptr(), ws.numel(),
+                                      _lib.stream_ptr()))
+        _lib.check(L.ppo_grad_reduce(S, A, ws.data_ptr(), ws.numel(), g.data_ptr(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return g.cpu().numpy()
+
+    P = flat0.numel()
+    g_again = grad_of(0, n, n)
+    assert np.array_equal(g_again[:P], g_full.cpu().numpy())
+    cut = (n * 3) // 8 + 5                                    # uneven, not a multiple of the tile
+    g_sum = grad_of(0, cut, n) + grad_of(cut, n, n)
+    assert max_abs(g_sum, g_again) < 2e-6 * np.abs(g_again).max()
+    # a 262 144-sample slice against the CPU restatement
+    m = 262144
+    Pd = O.unflatten_params(flat0.cpu().numpy(), S, A)
+    h = lambda t: t[:m].cpu().numpy()
+    out_w, grads_w = O.ppo_loss_and_grads(Pd, h(xs), h(acts), h(old), h(adv), h(ret), 0.2, True, 0.6)
+    want = O.flatten_params(grads_w)
+    got = grad_of(0, m, m)
+    assert max_abs(got[:P], want) < 1e-4 * np.abs(want).max()
+    assert rel_err(got[-2] + got[-1], out_w["loss_mean"]) < 1e-5
+
+
 def test_symmetric_wave_kernel_passes_the_same_parity_cases():
     """The alternative fwd/bwd kernel (symmetric waves on 16-sample tiles, PPO_FWDBWD=sym; the
     variable is read once per process) against the same restatement / golden cases, in a child

@@ -606,6 +606,41 @@ def test_single_state_session_survives_buffer_growth(eng):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cont", [False, True])
+def test_single_state_session_sees_in_place_weight_writes(eng, cont):
+    """The kernel that serves step k+1 is launched during step k and loads its weights then.  An
+    in-place write to policy_old's parameters between two steps - through the flat vector or through
+    one of the nn.Linear views, outside update() / load() / load_state_dict() - must still be seen
+    by the next step: its stored log-prob and value equal evaluate() under the NEW weights."""
+    ppo, _ = eng
+    S, A = (24, 4) if cont else (4, 2)
+    torch.manual_seed(3)
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, cont, 0.5 if cont else None)
+    xs = np.random.default_rng(4).standard_normal((6, S)).astype(np.float32)
+    agent.select_action(xs[0])
+    agent.select_action(xs[1])          # steady state: a kernel with the current weights waits for step 3
+    assert agent._act_session is not None
+    pol = agent.policy_old
+    writes = [lambda: pol.flat.mul_(0.5),
+              lambda: pol.actor[0].weight.add_(0.25),
+              lambda: pol.critic[4].bias.fill_(3.0),
+              lambda: pol.flat.copy_(agent.policy.flat * 1.5)]
+    for i, write in enumerate(writes):
+        with torch.no_grad():
+            write()
+        agent.select_action(xs[2 + i])
+        row = 2 + i
+        lp, v, _ = pol.evaluate(agent.buffer.rows("states", row, row + 1),
+                                agent.buffer.rows("actions", row, row + 1))
+        assert torch.equal(agent.buffer.rows("logprobs", row, row + 1), lp.reshape(1)), i
+        assert torch.equal(agent.buffer.rows("state_values", row, row + 1), v.reshape(1)), i
+    agent.close()
+    assert agent._act_session is None
+    agent.close()                        # idempotent
+    with pytest.raises(ValueError):
+        agent.select_action(np.zeros(1))         # a length-1 state is not broadcast into S inputs
+
+
 @pytest.mark.parametrize("cont,S,A", [(False, 4, 2), (True, 24, 6), (False, 63, 8)])
 def test_act_tile_shapes_agree(eng, cont, S, A):
     """Small batches run ppo_act / ppo_evaluate on 16-sample tiles (16x16x4 MFMA), large ones on
