@@ -189,7 +189,8 @@ def measure(config_key, cfg, steps, warmup, world, rank, custom_shape, with_cpu,
         iteration()
     barrier()
     dt = time.perf_counter() - t0
-    on_device = world > 1 and td.get_backend() == "nccl"
+    in_group = td.is_available() and td.is_initialized()      # (also the one-rank rehearsal group)
+    on_device = in_group and td.get_backend() == "nccl"
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_device else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -238,7 +239,7 @@ def measure(config_key, cfg, steps, warmup, world, rank, custom_shape, with_cpu,
 
     # what the first multi-rank run saw: backend, ranks, and whether the replicas agree bit for bit
     dist_info = None
-    if world > 1:
+    if in_group:
         flatp = agent.policy.flat.double()
         mine = torch.stack([flatp.sum(), flatp.abs().sum(), agent.last_loss[-1].double(),
                             agent.policy_old.flat.double().sum()])

@@ -96,7 +96,8 @@ int ppo_returns_scan_flat(const void* rewards, int rewards_are_f64, const uint8_
  * PPO_E_TOO_LARGE.  Results are identical to ppo_returns_scan_flat's, bit for bit.  Every call on
  * one GPU uses that GPU's one array: calls that overlap in time on the same GPU (different
  * streams or threads) race; calls on one stream, or on different GPUs, do not.  Nothing has to
- * be cleared between calls. */
+ * be cleared between calls.  `stream` must belong to the current device (PPO_E_BADARG otherwise):
+ * the array used is the current device's. */
 #define PPO_SCAN_NOALLOC_MAX (1 << 24)
 int ppo_returns_scan_flat_noalloc(const void* rewards, int rewards_are_f64, const uint8_t* terminals,
                                   int64_t n, double gamma, float* returns_out, double* moments_out,

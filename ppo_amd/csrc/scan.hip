@@ -407,6 +407,11 @@ extern "C" int ppo_returns_scan_flat_noalloc(const void* rewards, int rewards_ar
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return PPO_E_BADARG;
+    // the scratch address used below is the CURRENT device's: a stream of another device would run the
+    // kernels there, on an address that belongs to this one
+    hipDevice_t stream_dev = dev;
+    if (stream && hipStreamGetDevice((hipStream_t)stream, &stream_dev) == hipSuccess && (int)stream_dev != dev)
+        return PPO_E_BADARG;
     if (!scratch_addr[dev]) {  // first call on this device (which is current)
         void* p = nullptr;
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));

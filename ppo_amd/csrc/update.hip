@@ -845,8 +845,10 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
     a.stride_critic = stride_of(n_critic_params(state_dim));
     a.ws_header = (int*)workspace;
     a.partial_actor = (float*)((char*)workspace + FB_WS_HEADER);
-    // Symmetric-wave kernel (update_sym.hip) where selected; the forward/backward-pair kernel below
-    // otherwise.  PPO_FWDBWD=pair / sym forces one of them (cross-checks, A/B timing).
+    // Symmetric-wave kernel (update_sym.hip) where selected, in the library variant that carries it; the
+    // forward/backward-pair kernel below otherwise.  PPO_FWDBWD=pair / sym forces one of them there
+    // (cross-checks, A/B timing).
+#ifdef PPO_WITH_SYM   // the library variant that carries update_sym.hip (never the product's default)
     static const char* mode = getenv("PPO_FWDBWD");
     bool sym = fwdbwd_sym_default(state_dim, action_dim, n_local);
     if (mode && !strcmp(mode, "pair")) sym = false;
@@ -856,6 +858,7 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
         a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
         return launch_fwdbwd_sym(a, continuous, (hipStream_t)stream);
     }
+#endif
     role_wgs(action_dim, n_local, TILE_M, FB_PAIRS, a.n_actor_wg, a.n_critic_wg);
     a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
     hipStream_t st = (hipStream_t)stream;

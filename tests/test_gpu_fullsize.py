@@ -197,14 +197,16 @@ def test_c5_full_size_rollout_and_update(eng):
 
 
 def test_symmetric_wave_kernel_passes_the_same_parity_cases():
-    """The alternative fwd/bwd kernel (symmetric waves on 16-sample tiles, PPO_FWDBWD=sym; the
-    variable is read once per process) against the same restatement / golden cases, in a child
+    """The alternative fwd/bwd kernel (symmetric waves on 16-sample tiles; in libppo_hip_sym.so, selected
+    with PPO_FWDBWD=sym; the variable is read once per process) against the same restatement / golden cases, in a child
     process: every shape class it supports (S <= 31), the golden first-epoch and K-epoch cases."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, PPO_FWDBWD="sym")
+    lib = os.path.join(os.path.dirname(here), "ppo_amd", "libppo_hip_sym.so")   # the variant that carries it
+    assert os.path.exists(lib), "python -m ppo_amd.build makes libppo_hip_sym.so next to the product library"
+    env = dict(os.environ, PPO_FWDBWD="sym", PPO_HIP_LIB=lib)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"),
                         "-k", "every_shape_class or first_epoch_golden or k_epochs_golden or full_size_gradient"],

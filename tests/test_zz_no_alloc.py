@@ -38,6 +38,12 @@ def test_noalloc_scan_equals_workspace_scan_twice_second_smaller():
         assert np.array_equal(got, want), n
         assert np.array_equal(got_mom, want_mom), n
         assert got_mom[0] == n and np.isfinite(got).all()
+    # on a stream of its own (the stream's device is checked against the current one: same device here)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        got, got_mom = _scan(_lib, r, t, 0.99, f64, noalloc=True)
+    assert np.array_equal(got, want) and np.array_equal(got_mom, want_mom)
     # capacity: one element beyond the fixed maximum is refused with a clear error, nothing is launched
     cap = 1 << 24
     code = L.ppo_returns_scan_flat_noalloc(1, 0, 1, cap + 1, 0.99, 1, 1, None)

@@ -16,8 +16,8 @@ from ppo_amd import build as B
 
 LIB = os.environ.get("PPO_STAMPS_LIB", os.path.join(ROOT, "ppo_amd", "libppo_hip_stamps.so"))
 if "--build" in sys.argv:
-    srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DPPO_PHASE_STAMPS", "-shared"] + srcs + ["-o", LIB])
+    srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES + B.SYM_SOURCES]
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DPPO_PHASE_STAMPS", "-DPPO_WITH_SYM", "-shared"] + srcs + ["-o", LIB])
     sys.exit(0)
 
 from ppo_amd import _lib
