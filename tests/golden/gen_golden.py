@@ -383,7 +383,7 @@ def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal"), n_pe
                               per case: diameter of the set of end points, number of branches;
       <case>_branches.npz     the distinct end points (flat parameter vectors, 2e-5 apart or more):
                               a correct implementation in another summation order must land within
-                              1e-4 of ONE of them;
+                              1e-4 of ONE of them; with the optimizer's exp_avg / exp_avg_sq there;
       <case>_traj.npz         the golden run's flat parameter vector after selected epochs, and per
                               epoch the largest distance of any run from the golden run."""
     out = {"torch_version": str(torch.__version__), "cases": {}}
@@ -394,6 +394,8 @@ def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal"), n_pe
         T = int(d["T"])
         keys = [k[len("param/"):] for k in d if k.startswith("param/")]
         want = np.concatenate([d[f"K{K}/param/{k}"].reshape(-1) for k in keys])
+
+        last_state = [None]
 
         def run(threads, **kw):
             torch.set_num_threads(threads)
@@ -411,20 +413,29 @@ def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal"), n_pe
             with contextlib.redirect_stdout(io.StringIO()):
                 ag.update()
             torch.set_num_threads(1)
+            # Adam's moments at the end point, flat in the optimizer's parameter order (= state_dict order)
+            ps = [p for g in ag.optimizer.param_groups for p in g["params"]]
+            last_state[0] = tuple(torch.cat([ag.optimizer.state[p][kind].detach().reshape(-1) for p in ps])
+                                  .numpy().copy() for kind in ("exp_avg", "exp_avg_sq"))
             return np.stack(traj)
 
-        base = run(1)                       # rebuilding the agent from the arrays reproduces the golden
+        def run_s(threads, **kw):            # (trajectory, Adam moments at its end)
+            tr = run(threads, **kw)
+            return tr, last_state[0]
+
+        base, base_state = run_s(1)         # rebuilding the agent from the arrays reproduces the golden
         assert np.array_equal(base[-1], want), name
-        runs = {"threads4": run(4), "threads8": run(8),
-                "returns_as_rewards_same_order": run(1, returns_as_rewards=True),
-                "reversed_order": run(1, order=np.arange(T)[::-1], returns_as_rewards=True)}
+        runs = {"threads4": run_s(4), "threads8": run_s(8),
+                "returns_as_rewards_same_order": run_s(1, returns_as_rewards=True),
+                "reversed_order": run_s(1, order=np.arange(T)[::-1], returns_as_rewards=True)}
         rng = np.random.default_rng(1000 + T)
         for i in range(n_perm):
-            runs[f"permutation{i}"] = run(1, order=rng.permutation(T), returns_as_rewards=True)
+            runs[f"permutation{i}"] = run_s(1, order=rng.permutation(T), returns_as_rewards=True)
+        branch_states = [base_state]
         rec = {"K": K, "T": T, "runs": {}}
         branches, counts = [base[-1]], [1]
         curve = np.zeros(K)
-        for rn, tr in runs.items():
+        for rn, (tr, st) in runs.items():
             dev = np.abs(tr - base).max(axis=1)                     # per epoch
             curve = np.maximum(curve, dev)
             over = np.nonzero(dev > 1e-4)[0]
@@ -434,6 +445,7 @@ def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal"), n_pe
             dist = [float(np.abs(tr[-1] - b).max()) for b in branches]
             if min(dist) > 2e-5:
                 branches.append(tr[-1])
+                branch_states.append(st)
                 counts.append(1)
             else:
                 counts[int(np.argmin(dist))] += 1
@@ -444,8 +456,12 @@ def reference_spread(names=("c1_cartpole", "c2_lunarlander", "c3_bipedal"), n_pe
         rec["n_branches"] = len(branches)
         rec["branch_counts"] = counts
         out["cases"][name] = rec
+        # exp_avg / exp_avg_sq: the reference optimizer's moments at each end point (of the first run
+        # that reached it), so that an engine that lands on branch i can be checked against ITS state
         np.savez_compressed(os.path.join(HERE, name + "_branches.npz"), finals=fin,
-                            counts=np.asarray(counts))
+                            counts=np.asarray(counts),
+                            exp_avg=np.stack([s_[0] for s_ in branch_states]),
+                            exp_avg_sq=np.stack([s_[1] for s_ in branch_states]))
         snaps = sorted({k for k in (1, 2, 4, 8, 16, 24, 32, 48, 64, K) if k <= K})
         # spread_curve[e-1]: largest distance of any of the runs above from the golden run after epoch e
         np.savez_compressed(os.path.join(HERE, name + "_traj.npz"), epochs=np.asarray(snaps),

@@ -24,10 +24,22 @@ def load_trajectory(name):
     return [int(k) for k in z["epochs"]], {int(k): z[f"K{int(k)}"] for k in z["epochs"]}, z["spread_curve"]
 
 
-def nearest_branch_distance(flat_params, name):
-    """max |param - reference end point| for the closest of the reference's recorded end points."""
+def nearest_branch(flat_params, name):
+    """(max |param - reference end point|, index) for the closest of the reference's recorded end points
+    (index 0 is the golden run's own end point)."""
     fin = load_branches(name).astype(np.float64)
-    return float(np.abs(fin - np.asarray(flat_params, np.float64)[None, :]).max(axis=1).min())
+    dist = np.abs(fin - np.asarray(flat_params, np.float64)[None, :]).max(axis=1)
+    return float(dist.min()), int(dist.argmin())
+
+
+def nearest_branch_distance(flat_params, name):
+    return nearest_branch(flat_params, name)[0]
+
+
+def load_branch_state(name, index):
+    """The reference optimizer's (exp_avg, exp_avg_sq), flat, at recorded end point `index`."""
+    z = np.load(os.path.join(GOLDEN, name + "_branches.npz"))
+    return z["exp_avg"][index], z["exp_avg_sq"][index]
 
 
 def load_case(name):

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from helpers import (GOLDEN, TWO_UPDATE_CASES, UPDATE_CASES, case_params, load_case, load_trajectory,
-                     max_abs, nearest_branch_distance, rel_err)
+                     load_branch_state, max_abs, nearest_branch, nearest_branch_distance, rel_err)
 from oracle import ppo_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -404,15 +404,18 @@ def test_update_k_epochs_golden(eng, name):
         agent.update()
         torch.cuda.synchronize()
         got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
+        S, A = int(d["S"]), int(d["A"])
         if K <= 4:
             worst = max(max_abs(got[k], d[f"K{K}/param/{k}"]) for k in O.PARAM_KEYS)
+            check_adam_state(agent, lambda kind, k: d[f"K{K}/{kind}/{k}"], S, A)
         else:
-            worst = nearest_branch_distance(agent.policy.flat.cpu().numpy(), name)
+            # the reference's own end point this run lands on, and the reference optimizer's moments THERE
+            worst, idx = nearest_branch(agent.policy.flat.cpu().numpy(), name)
+            bm, bv = (O.unflatten_params(x, S, A) for x in load_branch_state(name, idx))
+            check_adam_state(agent, lambda kind, k: (bm if kind == "exp_avg" else bv)[k], S, A, tol=3e-4)
         assert worst < TOL_PARAM, (K, worst)
         assert rel_err(agent.last_loss.cpu().numpy(), d[f"K{K}/loss_mean_all"]) < 1e-4, K
         assert agent.optimizer.step_count == int(d[f"K{K}/step"])
-        if K <= 4:
-            check_adam_state(agent, lambda kind, k: d[f"K{K}/{kind}/{k}"], int(d["S"]), int(d["A"]))
 
 
 @pytest.mark.parametrize("name", ["c1_cartpole", "c2_lunarlander", "c3_bipedal"])
@@ -429,10 +432,12 @@ def test_update_trajectory_within_reference_spread(eng, name):
         assert dev < TOL_PARAM + float(curve[K - 1]), (K, dev)
 
 
-def check_adam_state(agent, want, S, A, tol=5e-4):
+def check_adam_state(agent, want, S, A, tol=1.5e-4):
     """exp_avg / exp_avg_sq of the engine's optimizer against the reference optimizer's state,
     per tensor, relative to the tensor's largest entry (the gradients they average agree to
-    <= 1e-4 of the tensor's max; the second moment squares them)."""
+    <= 1e-4 of the tensor's max).  Measured: <= 4.8e-5 after K <= 4 epochs, <= 9.9e-5 against the
+    nearest recorded end point's state after 30 / 80 epochs, <= 6.5e-6 after each of two
+    consecutive updates (tools/parity_report.py)."""
     m = O.unflatten_params(agent.optimizer.exp_avg.cpu().numpy(), S, A)
     v = O.unflatten_params(agent.optimizer.exp_avg_sq.cpu().numpy(), S, A)
     for k in O.PARAM_KEYS:
@@ -466,7 +471,7 @@ def test_two_consecutive_updates_golden(eng, name):
         got = {k: v.cpu().numpy() for k, v in agent.policy.state_dict().items()}
         worst = max(max_abs(got[k], d[f"u{u}/after/param/{k}"]) for k in O.PARAM_KEYS)
         assert worst < TOL_PARAM, (u, worst)
-        check_adam_state(agent, lambda kind, k: d[f"u{u}/after/{kind}/{k}"], S, A, tol=2e-3)
+        check_adam_state(agent, lambda kind, k: d[f"u{u}/after/{kind}/{k}"], S, A, tol=5e-5)
         assert rel_err(agent.last_loss.cpu().numpy(), d[f"u{u}/loss_mean_all"]) < 1e-4
 
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Runs only the K-epoch update chain on a synthetic C4/C5-shaped buffer (for rocprofv3 passes).
+"""Runs one iteration of the default product path (fused rollout + update()) on a synthetic C4/C5-shaped
+buffer (for rocprofv3 passes).
 usage: python3 tools/prof_fwdbwd.py [c4|c5] [epochs]"""
 import contextlib
 import io
@@ -21,16 +22,8 @@ S, A, N, T = cfg["S"], cfg["A"], cfg["n_envs"], cfg["horizon"]
 torch.manual_seed(0)
 agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, epochs, 0.2, cfg["continuous"], cfg["std"])
 agent.buffer.reserve(N * T)
-L = _lib.lib()
-for t in range(T):
-    xs = agent.next_state_slot(N)
-    rs, ds = agent.buffer.claim_env_slots(N)
-    _lib.check(L.ppo_synth_env_step(xs.data_ptr(), rs.data_ptr(), ds.data_ptr(), N, S,
-                                    cfg["reward_kind"], cfg["p_terminal"], t, T, 1234,
-                                    _lib.stream_ptr()))
-    agent.act_inplace(N)
-agent.kernel_events = []
+# the product path: one persistent rollout kernel, then update() through ppo_update_epochs
+agent.synthetic_rollout(N, T, cfg["reward_kind"], cfg["p_terminal"])
 agent.update()
 torch.cuda.synchronize()
-ms = [a.elapsed_time(b) for a, b in agent.kernel_events]
-print("fwdbwd ms per launch:", " ".join(f"{m:.4f}" for m in ms), "loss", agent.last_loss.tolist()[-1])
+print("loss", agent.last_loss.tolist()[-1])
