@@ -159,7 +159,9 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                     z1 = mfma32(L.w1t[k * HID + 32 + c], xf[s], z1);
                 }
             }
-            load_xf(min(tile + ctx.tstride, ctx.n_tiles - 1) * TILE_M, half_s);  // next tile's
+            // next tile's observations: right away for narrow inputs; for S >= 32 (32 registers) only at
+            // the end of the iteration, when the activations are dead
+            if constexpr (L1 < 2) load_xf(min(tile + ctx.tstride, ctx.n_tiles - 1) * TILE_M, half_s);
             H1[0] = tanh16_prescaled(z0);
             H1[1] = tanh16_prescaled(z1);
         }
@@ -271,6 +273,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             }
         }
         STAMP(4)
+        if constexpr (L1 == 2) load_xf(min(tile + ctx.tstride, ctx.n_tiles - 1) * TILE_M, half_s);
         __syncthreads();  // buffers of this tile are complete
         STAMP(5)
     }
@@ -368,6 +371,13 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         // ahead of the barriers so that they are long there when needed (lines the partner loaded a
         // tile ago).  Wide: xp[s][jt] = X_aug[16h+s][32*jt+c].  Narrow: xq[s] = X_aug[4s+q4][c16].
         const bool full = m0 + TILE_M <= a.n;
+        // (S >= 32 only; the base goes through readfirstlane so that it provably lives in scalar registers)
+        auto row_base = [&](int row) {
+            const uint64_t p = reinterpret_cast<uint64_t>(a.states + (m0 + row) * S);
+            const uint64_t u = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p) |
+                               (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32;
+            return reinterpret_cast<const char*>(u);
+        };
         if constexpr (NARROW) {
             const float fill = c16 == S ? 1.0f : 0.0f;
             const int inc = min(c16, S - 1);
@@ -392,7 +402,17 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                 const int in = 32 * jt + c;
                 const float fill = in == S ? 1.0f : 0.0f;
                 const int inc = min(in, S - 1);
-                if (full) {
+                if (full && L1 == 2) {
+                    // 32 loads: (scalar row base of k-step s) + (this lane's 32-bit byte offset, the same
+                    // for every tile) instead of 32 loop-invariant 64-bit addresses, which would not fit
+                    // next to the 128 accumulator registers
+                    const unsigned voff = (unsigned)(16 * h * S + inc) * 4u;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const float v = *reinterpret_cast<const float*>(row_base(s) + voff);
+                        xp[s][jt] = in < S ? v : fill;
+                    }
+                } else if (full) {
                     const float* p0 = a.states + (m0 + 16 * h) * S + inc;
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
@@ -435,13 +455,26 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         }
     };
 
+    auto wgrad2 = [&]() {
+        // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a0 = zcol[s * W2_LD];
+            const float a1 = zcol[s * W2_LD + 32];
+            const float b0 = hcol[s * W2_LD];
+            const float b1 = hcol[s * W2_LD + 32];
+            gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
+            gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
+            gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
+            gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
+        }
+    };
+
     for (int it = 0; it < ctx.n_iter; ++it) {
         const int64_t tile = ctx.tile0 + (int64_t)it * ctx.tstride;
         STAMP_START
         if constexpr (DEFER) {
             if (it > 0) load_x((tile - ctx.tstride) * TILE_M);   // operands of the deferred wgrad
-        } else {
-            load_x(tile * TILE_M);
         }
         STAMP(0)
         __syncthreads();  // (forward wave: previous buffers may be overwritten)
@@ -452,6 +485,13 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         __syncthreads();  // buffers of this tile are complete
         STAMP(2)
 
+        // S >= 32 (128 accumulator registers): the layer-2 wgrad runs FIRST, so that dH1's 32 registers
+        // are not live across it, and the layer-1 wgrad's 32 operand registers are fetched only after
+        // it (their latency passes under the dgrad)
+        if constexpr (!DEFER) {
+            wgrad2();
+            load_x(tile * TILE_M);
+        }
         // ---------------- dgrad of layer 2: dH1[in, m] = sum_out W2[out, in] dZ2[m, out]; the four
         // k-steps of group g are output units 8g + 4h .. +3: one 16-byte load per operand
         f32x16 d0 = {0}, d1 = {0};
@@ -480,18 +520,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             }
         }
         STAMP(4)
-        // ---------------- wgrad of layer 2: dW2[o, i] += sum_m dZ2[m, o] H1[m, i]
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float a0 = zcol[s * W2_LD];
-            const float a1 = zcol[s * W2_LD + 32];
-            const float b0 = hcol[s * W2_LD];
-            const float b1 = hcol[s * W2_LD + 32];
-            gW2[0][0] = mfma32(a0, b0, gW2[0][0]);
-            gW2[0][1] = mfma32(a0, b1, gW2[0][1]);
-            gW2[1][0] = mfma32(a1, b0, gW2[1][0]);
-            gW2[1][1] = mfma32(a1, b1, gW2[1][1]);
-        }
+        if constexpr (DEFER) wgrad2();
         STAMP(5)
         // ---------------- dZ1 goes to its own buffer (S <= 31) or takes dZ2's place (this wave's
         // own reads of dZ2 are complete: LDS operations of one wave execute in order)

@@ -35,7 +35,11 @@ def main():
         else:
             name, path = args[i].split("=", 1)
             libs.append((name, os.path.abspath(path))); i += 1
-    cfg = dict(CONFIGS[cfg_name])
+    if cfg_name.startswith("wide"):     # wideS_A: a 524 288-sample buffer with S-wide observations (not a BASELINE config)
+        S_, A_ = (int(v) for v in cfg_name[4:].split("_"))
+        cfg = dict(CONFIGS["c4"], S=S_, A=A_)
+    else:
+        cfg = dict(CONFIGS[cfg_name])
     S, A, N, T = cfg["S"], cfg["A"], cfg["n_envs"], cfg["horizon"]
     from ppo_amd import _lib
     agents = []
