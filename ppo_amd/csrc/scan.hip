@@ -11,6 +11,7 @@
 // Only the carries go through re-associated arithmetic (relative error ~1e-16 before the fp32
 // rounding); everything inside a thread's 8 elements is the reference's operation order.
 #include "ppo_common.h"
+#include <cstdlib>
 
 #define SCAN_BLOCK 256
 #define SCAN_E 8
@@ -59,8 +60,10 @@ __device__ __forceinline__ Mom merge(const Mom& x, const Mom& y) {  // Chan et a
     return o;
 }
 
-__device__ __forceinline__ Mom block_merge(Mom v, Mom* lds /* >= 4 */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Merge over a group of `nwaves` consecutive waves (all threads of the workgroup call it: one barrier
+// inside); lds: >= nwaves entries of the group's own.  Lanes merge by shuffles, then the waves in order.
+__device__ __forceinline__ Mom group_merge(Mom v, Mom* lds, int wave_in_group, int nwaves) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         Mom o;
@@ -69,11 +72,15 @@ __device__ __forceinline__ Mom block_merge(Mom v, Mom* lds /* >= 4 */) {
         o.m2 = __shfl_down(v.m2, off);
         if (lane + off < 64) v = merge(v, o);
     }
-    if (lane == 0) lds[wave] = v;
+    if (lane == 0) lds[wave_in_group] = v;
     __syncthreads();
     Mom t = lds[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = merge(t, lds[w]);
+    for (int w = 1; w < nwaves; ++w) t = merge(t, lds[w]);
     return t;
+}
+
+__device__ __forceinline__ Mom block_merge(Mom v, Mom* lds /* >= 4 */) {
+    return group_merge(v, lds, threadIdx.x >> 6, (int)(blockDim.x >> 6));
 }
 
 template <typename RT>
@@ -129,9 +136,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_flat_reduce(const RT* __restr
 }
 
 // One wave: carry entering block b (the return just right of its last element) for all blocks.
-__global__ __launch_bounds__(64) void scan_flat_carries(const Aff* __restrict__ block_aff, int nb,
-                                                        double* __restrict__ carries) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void carries_of_blocks(const Aff* block_aff, int nb, double* carries, int lane) {
     const int per = (nb + 63) / 64;
     const int lo = lane * per, hi = min(nb, lo + per);
     Aff f;
@@ -146,6 +151,43 @@ __global__ __launch_bounds__(64) void scan_flat_carries(const Aff* __restrict__ 
         carries[b] = carry;
         carry = block_aff[b].b + block_aff[b].a * carry;
     }
+}
+
+__global__ __launch_bounds__(64) void scan_flat_carries(const Aff* __restrict__ block_aff, int nb,
+                                                        double* __restrict__ carries) {
+    carries_of_blocks(block_aff, nb, carries, threadIdx.x);
+}
+
+// A thread's 8 elements from the carry entering them: the reference's own recurrence, one rounding per
+// multiply and per add (Python floats), rounded to fp32 once (PPO.py:211); leaves the thread's moments.
+__device__ __forceinline__ Mom apply_elems(const double (&r)[SCAN_E], const bool (&term)[SCAN_E], int64_t base,
+                                           int64_t n, double gamma, double d, float* __restrict__ returns) {
+    float out[SCAN_E];
+    double sum = 0.0;
+    int cnt = 0;
+#pragma unroll
+    for (int j = SCAN_E - 1; j >= 0; --j) {
+        if (base + j < n) {
+            if (term[j]) d = 0.0;
+            d = __dadd_rn(r[j], __dmul_rn(gamma, d));
+            out[j] = (float)d;
+            sum += (double)out[j];
+            ++cnt;
+        }
+    }
+    Mom m;
+    m.n = (double)cnt;
+    m.mean = cnt ? sum / cnt : 0.0;
+    m.m2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_E; ++j) {
+        if (base + j < n) {
+            returns[base + j] = out[j];
+            const double dd = (double)out[j] - m.mean;
+            m.m2 += dd * dd;
+        }
+    }
+    return m;
 }
 
 template <typename RT>
@@ -176,33 +218,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_flat_apply(const RT* __restri
     __syncthreads();
     Aff x = shfl_down_aff(s, 1);
     if (lane == 63) { x.a = 1.0; x.b = 0.0; }
-    double d = x.b + x.a * wcarry[wave];
-    // the reference's own recurrence, one rounding per multiply and per add (Python floats)
-    float out[SCAN_E];
-    double sum = 0.0;
-    int cnt = 0;
-#pragma unroll
-    for (int j = SCAN_E - 1; j >= 0; --j) {
-        if (base + j < n) {
-            if (term[j]) d = 0.0;
-            d = __dadd_rn(r[j], __dmul_rn(gamma, d));
-            out[j] = (float)d;
-            sum += (double)out[j];
-            ++cnt;
-        }
-    }
-    Mom m;
-    m.n = (double)cnt;
-    m.mean = cnt ? sum / cnt : 0.0;
-    m.m2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < SCAN_E; ++j) {
-        if (base + j < n) {
-            returns[base + j] = out[j];
-            const double dd = (double)out[j] - m.mean;
-            m.m2 += dd * dd;
-        }
-    }
+    const double d0 = x.b + x.a * wcarry[wave];
+    const Mom m = apply_elems(r, term, base, n, gamma, d0, returns);
     const Mom bm = block_merge(m, mom_lds);
     if (threadIdx.x == 0) block_mom[blockIdx.x] = bm;
 }
@@ -262,18 +279,84 @@ __global__ __launch_bounds__(ROWS_BLOCK) void scan_rows_kernel(const float* __re
     if (threadIdx.x == 0) block_mom[blockIdx.x] = bm;
 }
 
-__global__ __launch_bounds__(256) void moments_finalize(const Mom* __restrict__ block_mom, int nb,
-                                                        double* __restrict__ out3) {
-    __shared__ Mom mom_lds[4];
+// The block moments merged in sequence order by 256 threads (`group` = their wave group of four, see
+// group_merge); thread 0 of the group returns the total.
+__device__ __forceinline__ Mom finalize_moments(const Mom* block_mom, int nb, int t256, Mom* lds) {
     Mom m;
     m.n = 0.0;
     m.mean = 0.0;
     m.m2 = 0.0;
     // contiguous segments keep the merge order equal to the sequence order
     const int per = (nb + 255) / 256;
-    const int lo = threadIdx.x * per, hi = min(nb, lo + per);
+    const int lo = t256 * per, hi = min(nb, lo + per);
     for (int b = lo; b < hi; ++b) m = merge(m, block_mom[b]);
-    const Mom t = block_merge(m, mom_lds);
+    return group_merge(m, lds, t256 >> 6, 4);
+}
+
+__global__ __launch_bounds__(256) void moments_finalize(const Mom* __restrict__ block_mom, int nb,
+                                                        double* __restrict__ out3) {
+    __shared__ Mom mom_lds[4];
+    const Mom t = finalize_moments(block_mom, nb, threadIdx.x, mom_lds);
+    if (threadIdx.x == 0) {
+        out3[0] = t.n;
+        out3[1] = t.mean;
+        out3[2] = t.m2;
+    }
+}
+
+// The whole flat scan in ONE launch for sequences of up to SCAN_SMALL_MAX steps (the reference's buffers
+// are 900-6000 steps): one workgroup of 1024 threads acts as four 256-thread blocks of the three-launch
+// form above - same composition order per block, the same carries_of_blocks, apply_elems and moment
+// merges - with the block aggregates, carries and block moments in LDS instead of a workspace, so the
+// returns and moments are bit-identical to the three-launch form's.
+#define SCAN_SMALL_BLOCKS 4
+#define SCAN_SMALL_MAX (SCAN_SMALL_BLOCKS * SCAN_CHUNK)
+template <typename RT>
+__global__ __launch_bounds__(SCAN_SMALL_BLOCKS * SCAN_BLOCK) void scan_flat_small(
+    const RT* __restrict__ rewards, const uint8_t* __restrict__ terminals, int64_t n, double gamma,
+    float* __restrict__ returns, double* __restrict__ out3) {
+    constexpr int WPB = SCAN_BLOCK / 64;                 // waves per virtual block
+    __shared__ Aff wav[SCAN_SMALL_BLOCKS * WPB];
+    __shared__ Aff block_aff[SCAN_SMALL_BLOCKS];
+    __shared__ double carries[SCAN_SMALL_BLOCKS];
+    __shared__ double wcarry[SCAN_SMALL_BLOCKS * WPB];
+    __shared__ Mom mom_lds[SCAN_SMALL_BLOCKS * WPB];
+    __shared__ Mom block_mom[SCAN_SMALL_BLOCKS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int vb = threadIdx.x / SCAN_BLOCK, tl = threadIdx.x % SCAN_BLOCK;   // virtual block, thread in it
+    const int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    const int64_t base = (int64_t)vb * SCAN_CHUNK + (int64_t)tl * SCAN_E;
+    double r[SCAN_E];
+    bool term[SCAN_E];
+    load_elems(rewards, terminals, base, n, r, term);
+    const Aff s = wave_suffix(thread_aff(r, term, base, n, gamma), lane);
+    if (lane == 0) wav[wave] = s;
+    __syncthreads();
+    if (tl == 0) {                                       // (scan_flat_reduce's last step)
+        Aff t = wav[vb * WPB];
+        for (int w = 1; w < WPB; ++w) t = compose(t, wav[vb * WPB + w]);
+        block_aff[vb] = t;
+    }
+    __syncthreads();
+    if (wave == 0) carries_of_blocks(block_aff, nb, carries, lane);
+    __syncthreads();
+    if (tl == 0 && vb < nb) {                            // (scan_flat_apply's carry per wave)
+        double c = carries[vb];
+        for (int w = WPB - 1; w >= 0; --w) {
+            wcarry[vb * WPB + w] = c;
+            c = wav[vb * WPB + w].b + wav[vb * WPB + w].a * c;
+        }
+    }
+    __syncthreads();
+    Aff x = shfl_down_aff(s, 1);
+    if (lane == 63) { x.a = 1.0; x.b = 0.0; }
+    const double d0 = x.b + x.a * wcarry[wave];          // (a block past the end holds no element: unused)
+    const Mom m = apply_elems(r, term, base, n, gamma, d0, returns);
+    const Mom bm = group_merge(m, mom_lds + vb * WPB, wave % WPB, WPB);
+    if (tl == 0) block_mom[vb] = bm;
+    __syncthreads();
+    // (moments_finalize: its 256 threads are virtual block 0; the other groups merge nothing)
+    const Mom t = finalize_moments(block_mom, vb == 0 ? nb : 0, tl, mom_lds + vb * WPB);
     if (threadIdx.x == 0) {
         out3[0] = t.n;
         out3[1] = t.mean;
@@ -339,6 +422,12 @@ size_t ppo_scan_ws_bytes(int64_t n) {
            align_up(m * sizeof(Mom), 256);
 }
 
+// PPO_SCAN_SMALL=0 keeps short sequences on the three-launch form (cross-check of the two forms).
+static bool scan_small_off() {
+    static const bool off = [] { const char* e = getenv("PPO_SCAN_SMALL"); return e && e[0] == '0'; }();
+    return off;
+}
+
 // The three launches of the flat scan + the moments merge, on scratch carved by the caller:
 // aff[nb + 1], carries[nb + 1], mom[nb + 1] with nb = ceil(n / SCAN_CHUNK).  Every entry a kernel
 // reads has been written by an earlier kernel of the same call: the scratch needs no clearing.
@@ -346,6 +435,15 @@ static int launch_scan_flat(const void* rewards, int rewards_are_f64, const uint
                             int64_t n, double gamma, float* returns_out, double* moments_out,
                             Aff* aff, double* carries, Mom* mom, hipStream_t st) {
     const int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    if (n <= SCAN_SMALL_MAX && !scan_small_off()) {   // one launch instead of four; same bits
+        if (rewards_are_f64)
+            scan_flat_small<double><<<1, SCAN_SMALL_BLOCKS * SCAN_BLOCK, 0, st>>>((const double*)rewards, terminals, n,
+                                                                               gamma, returns_out, moments_out);
+        else
+            scan_flat_small<float><<<1, SCAN_SMALL_BLOCKS * SCAN_BLOCK, 0, st>>>((const float*)rewards, terminals, n,
+                                                                              gamma, returns_out, moments_out);
+        return (int)hipGetLastError();
+    }
     if (rewards_are_f64) {
         scan_flat_reduce<double><<<nb, SCAN_BLOCK, 0, st>>>((const double*)rewards, terminals, n,
                                                             gamma, aff);

@@ -343,6 +343,60 @@ def test_select_action_reference_surface(eng):
     assert len(cagent.buffer.actions) == 0
 
 
+def _flat_scan_cases():
+    rng = np.random.default_rng(77)
+    cases = []
+    for n, p, f64 in [(2, 0.5, False), (63, 0.1, True), (257, 0.0, False), (900, 1 / 300, True), (1600, 1 / 200, True),
+                      (2048, 0.01, False), (2049, 0.01, True), (6000, 1 / 1500, True), (8191, 0.002, False),
+                      (8192, 0.002, True)]:
+        r = rng.standard_normal(n)
+        cases.append((r if f64 else r.astype(np.float32), (rng.random(n) < p).astype(np.uint8), f64))
+    return cases
+
+
+def _run_flat_scans(_lib):
+    L = _lib.lib()
+    outs = []
+    for r, t, f64 in _flat_scan_cases():
+        n = r.size
+        rd, td_ = torch.from_numpy(r).cuda(), torch.from_numpy(t).cuda()
+        ret = torch.empty(n, dtype=torch.float32, device="cuda")
+        mom = torch.empty(3, dtype=torch.float64, device="cuda")
+        ws = torch.empty(L.ppo_workspace_bytes(4, 2, n), dtype=torch.uint8, device="cuda")
+        _lib.check(L.ppo_returns_scan_flat(rd.data_ptr(), int(f64), td_.data_ptr(), n, 0.99, ret.data_ptr(),
+                                           mom.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((ret.cpu().numpy(), mom.cpu().numpy()))
+    return outs
+
+
+def test_single_launch_flat_scan_equals_three_launch_form(eng, tmp_path):
+    """Sequences of up to 8192 steps take a single-workgroup kernel (one launch instead of four).  Its
+    returns are the oracle's bit for bit, and returns AND moments equal the three-launch form's bit
+    for bit (a child process with PPO_SCAN_SMALL=0 runs the same cases through that form)."""
+    import subprocess
+    import sys
+    _, _lib = eng
+    got = _run_flat_scans(_lib)
+    for (r, t, f64), (ret, mom) in zip(_flat_scan_cases(), got):
+        want = O.returns_scan(r, t.astype(bool), 0.99)
+        assert np.array_equal(ret, want.astype(np.float32)), r.size
+        assert mom[0] == r.size and abs(mom[1] - ret.astype(np.float64).mean()) < 1e-12 * max(1.0, abs(mom[1]))
+    out = tmp_path / "three_launch.npz"
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from ppo_amd import _lib\nimport test_gpu_parity as T\n"
+            "o = T._run_flat_scans(_lib)\n"
+            "np.savez(%r, **{f'r{i}': a for i, (a, _) in enumerate(o)}, **{f'm{i}': b for i, (_, b) in enumerate(o)})\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), str(out)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PPO_SCAN_SMALL="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    z = np.load(out)
+    for i, (ret, mom) in enumerate(got):
+        assert np.array_equal(ret, z[f"r{i}"]), i
+        assert np.array_equal(mom, z[f"m{i}"]), i
+
+
 # ------------------------------------------------------------------------------ update
 def agent_from_case(ppo, d, K):
     cont = bool(d["continuous"])
