@@ -75,6 +75,19 @@ int ppo_evaluate(const float* params, int state_dim, int action_dim, int continu
                  float action_var, const float* states, const void* actions, int64_t n,
                  float* logprobs, float* values, float* entropy, void* stream);
 
+/* Vector-Jacobian product of ppo_evaluate w.r.t. the parameters: given dL/dlogprob, dL/dvalue and
+ * dL/dentropy per sample (each float[n], or NULL for zeros), writes dL/dparams (flat, state_dict order)
+ * into grad_params_out, which must hold param_count + 2 floats (the last two are scratch).
+ * replaces: loss.backward() through policy.evaluate, PPO.py:227,244 (autograd over PPO.py:102-121), for
+ * any loss a caller builds from evaluate()'s outputs; ppo_epoch_fwdbwd is this with PPO.py:233-240's
+ * own seeds computed in the kernel.  The clamp of the Categorical's probabilities passes gradient on the
+ * closed interval and the Gaussian's entropy has none, as in torch.  workspace: ppo_workspace_bytes(). */
+int ppo_evaluate_backward(const float* params, int state_dim, int action_dim, int continuous,
+                          float action_var, const float* states, const void* actions, int64_t n,
+                          const float* grad_logprobs, const float* grad_values,
+                          const float* grad_entropy, float* grad_params_out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* ---- returns -------------------------------------------------------------------------------
  * Monte-Carlo discounted returns with terminal resets over ONE flat sequence, fp64 carry,
  * rounded once to fp32, plus the moments of the rounded returns.

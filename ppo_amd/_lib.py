@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to before d
 HERE = os.path.dirname(os.path.abspath(__file__))
 # PPO_HIP_LIB: diagnostic builds of the same sources (python -m ppo_amd.build --variant ...)
 LIB_PATH = os.environ.get("PPO_HIP_LIB") or os.path.join(HERE, "libppo_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _SIGNATURES = {
     "ppo_hip_abi_version": (c_int, []),
@@ -22,6 +22,8 @@ _SIGNATURES = {
                         c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppo_evaluate": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int64,
                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppo_evaluate_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int64,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ppo_returns_scan_flat": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_double, c_void_p,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     "ppo_returns_scan_flat_noalloc": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_double, c_void_p,

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppo_hip.so")
 LIB_SYM = os.path.join(HERE, "libppo_hip_sym.so")
-SOURCES = ["scan.hip", "act.hip", "act_one.hip", "update.hip", "env.hip", "rollout.hip"]
+SOURCES = ["scan.hip", "act.hip", "act_one.hip", "update.hip", "update_vjp.hip", "env.hip", "rollout.hip"]
 SYM_SOURCES = ["update_sym.hip"]             # + update.hip compiled with -DPPO_WITH_SYM
 HEADERS = ["ppo_common.h", "update_common.h", os.path.join("..", "..", "include", "ppo_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
@@ -25,7 +25,7 @@ def _stale(lib, sources):
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, s) for s in sources + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in sources + HEADERS] + [os.path.abspath(__file__)]   # (update_vjp.hip includes update.hip)
     return any(os.path.getmtime(d) > t for d in deps)
 
 

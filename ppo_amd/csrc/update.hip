@@ -32,6 +32,14 @@
 #include <cstring>
 
 #define FB_PAIRS 4
+// update_vjp.hip compiles this file once more with PPO_FWDBWD_SEEDED defined: the same kernel with the
+// caller's per-sample gradients as seeds (update_common.h), under another name, behind
+// ppo_evaluate_backward; everything else of this file belongs to the unseeded build only.
+#ifdef PPO_FWDBWD_SEEDED
+#define FWDBWD_KERNEL fwdbwd_vjp_kernel
+#else
+#define FWDBWD_KERNEL fwdbwd_kernel
+#endif
 #define FB_THREADS (FB_PAIRS * 2 * 64)
 // Per-pair hand-off space.  Rows are samples, columns hidden units, row stride W2_LD (= 68: 16-byte
 // aligned rows whose starts are 4 banks apart, so 16-byte accesses of 8 consecutive rows and 4-byte
@@ -46,7 +54,9 @@
 
 // Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
 // wave, written to a buffer registered with ppo_debug_set_stamps().  Never compiled into the product.
-#ifdef PPO_PHASE_STAMPS
+#if defined(PPO_PHASE_STAMPS) && defined(PPO_FWDBWD_SEEDED)
+static unsigned long long* g_stamp_buf = nullptr;
+#elif defined(PPO_PHASE_STAMPS)
 static unsigned long long* g_stamp_buf = nullptr;
 extern "C" void ppo_debug_set_stamps(void* p) { g_stamp_buf = (unsigned long long*)p; }
 #define STAMP_DECL unsigned long long st_acc[12] = {0}; unsigned long long st_prev = 0;
@@ -624,7 +634,7 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
 }
 
 template <bool CONT, int AMAX, int L1>
-__global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs a) {
+__global__ __launch_bounds__(FB_THREADS, 2) void FWDBWD_KERNEL(const FwdBwdArgs a) {
     extern __shared__ __align__(16) float smem[];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.ws_header[0] = a.n_actor_wg;
@@ -636,6 +646,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void fwdbwd_kernel(const FwdBwdArgs 
         run_role<HEAD_VALUE, 1, L1>(a, smem);
 }
 
+#ifndef PPO_FWDBWD_SEEDED
 // grad[p] = sum over the role's workgroups (fixed order, fp64 accumulate).  One block per 64
 // parameters: 4 row groups x 64 columns, the 4 partial sums combined in fixed order through LDS.
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial_actor,
@@ -747,6 +758,8 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(const float* __restric
         loss_out[0] = gsh[P & 63] + gsh[(P + 1) & 63];
 }
 
+#endif  // !PPO_FWDBWD_SEEDED
+
 // ---------------------------------------------------------------------------- host side
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 size_t ppo_scan_ws_bytes(int64_t n);  // scan.hip
@@ -797,6 +810,7 @@ static size_t update_ws_bytes(int S, int A) {
            align_up((size_t)FB_MAX_ROLE_WGS * stride_of(n_critic_params(S)) * sizeof(float), 256);
 }
 
+#ifndef PPO_FWDBWD_SEEDED
 extern "C" size_t ppo_workspace_bytes(int state_dim, int action_dim, int64_t max_samples) {
     if (state_dim < 1 || action_dim < 1 || max_samples < 1) return 0;
     const size_t a = update_ws_bytes(state_dim, action_dim);
@@ -809,6 +823,8 @@ extern "C" int64_t ppo_param_count(int state_dim, int action_dim, int64_t* n_act
     if (n_actor_out) *n_actor_out = na;
     return (int64_t)na + n_critic_params(state_dim);
 }
+
+#endif  // !PPO_FWDBWD_SEEDED
 
 static size_t fwdbwd_lds_bytes(int S, int A, int amax, int l1) {
     const int net = round4(net_lds_floats(S, amax, true));
@@ -823,15 +839,92 @@ static int launch_fwdbwd(const FwdBwdArgs& a, hipStream_t st) {
     if (lds > 160 * 1024) return PPO_E_UNSUPPORTED;
     static size_t configured = 0;
     if (lds > configured) {
-        const hipError_t e = hipFuncSetAttribute((const void*)fwdbwd_kernel<CONT, AMAX, L1>,
+        const hipError_t e = hipFuncSetAttribute((const void*)FWDBWD_KERNEL<CONT, AMAX, L1>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = lds;
     }
-    fwdbwd_kernel<CONT, AMAX, L1><<<a.n_actor_wg + a.n_critic_wg, FB_THREADS, lds, st>>>(a);
+    FWDBWD_KERNEL<CONT, AMAX, L1><<<a.n_actor_wg + a.n_critic_wg, FB_THREADS, lds, st>>>(a);
     return (int)hipGetLastError();
 }
 
+// Role split, workspace carve and launch of the fused kernel for arguments filled by the caller.
+static int fwdbwd_dispatch(FwdBwdArgs& a, int continuous, void* workspace, hipStream_t st) {
+    const int state_dim = a.S, action_dim = a.A;
+#ifdef PPO_PHASE_STAMPS
+    a.stamps = g_stamp_buf;
+#else
+    a.stamps = nullptr;
+#endif
+    a.stride_actor = stride_of(n_actor_params(state_dim, action_dim));
+    a.stride_critic = stride_of(n_critic_params(state_dim));
+    a.ws_header = (int*)workspace;
+    a.partial_actor = (float*)((char*)workspace + FB_WS_HEADER);
+    // Symmetric-wave kernel (update_sym.hip) where selected, in the library variant that carries it; the
+    // forward/backward-pair kernel below otherwise.  PPO_FWDBWD=pair / sym forces one of them there
+    // (cross-checks, A/B timing).
+#if defined(PPO_WITH_SYM) && !defined(PPO_FWDBWD_SEEDED)   // the library variant that carries update_sym.hip
+    static const char* mode = getenv("PPO_FWDBWD");
+    bool sym = fwdbwd_sym_default(state_dim, action_dim, a.n);
+    if (mode && !strcmp(mode, "pair")) sym = false;
+    if (mode && !strcmp(mode, "sym")) sym = fwdbwd_sym_supported(state_dim, action_dim);
+    if (sym) {
+        role_wgs(action_dim, a.n, 16, 8, a.n_actor_wg, a.n_critic_wg);
+        a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
+        return launch_fwdbwd_sym(a, continuous, st);
+    }
+#endif
+    role_wgs(action_dim, a.n, TILE_M, FB_PAIRS, a.n_actor_wg, a.n_critic_wg);
+    a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
+    const int l1 = state_dim + 1 <= 16 ? 0 : (state_dim + 1 <= 32 ? 1 : 2);
+    const int amax = action_dim <= 2 ? 2 : (action_dim <= 4 ? 4 : 8);
+#define FB_DISPATCH_L1(C, AM)                                                            \
+    if (l1 == 0) return launch_fwdbwd<C, AM, 0>(a, st);                                  \
+    if (l1 == 1) return launch_fwdbwd<C, AM, 1>(a, st);                                  \
+    return launch_fwdbwd<C, AM, 2>(a, st);
+#define FB_DISPATCH(C)                                                                   \
+    if (amax == 2) { FB_DISPATCH_L1(C, 2) }                                              \
+    if (amax == 4) { FB_DISPATCH_L1(C, 4) }                                              \
+    FB_DISPATCH_L1(C, 8)
+    if (continuous) { FB_DISPATCH(true) }
+    FB_DISPATCH(false)
+#undef FB_DISPATCH
+#undef FB_DISPATCH_L1
+}
+
+#ifdef PPO_FWDBWD_SEEDED
+// The vector-Jacobian product of ActorCritic.evaluate (PPO.py:102-121) w.r.t. the parameters: what
+// loss.backward() computes in the reference (PPO.py:244) for ANY loss built from evaluate()'s three
+// outputs.  Same fused kernel, seeded with the caller's per-sample gradients.
+extern "C" int ppo_evaluate_backward(const float* params, int state_dim, int action_dim, int continuous,
+                                     float action_var, const float* states, const void* actions, int64_t n,
+                                     const float* grad_logprobs, const float* grad_values,
+                                     const float* grad_entropy, float* grad_params_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!params || !states || !actions || !grad_params_out || n <= 0) return PPO_E_BADARG;
+    if (state_dim < 1 || state_dim > PPO_MAX_STATE_DIM || action_dim < 1 ||
+        action_dim > PPO_MAX_ACTION_DIM)
+        return PPO_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
+    FwdBwdArgs a{};
+    a.params = params;
+    a.S = state_dim;
+    a.A = action_dim;
+    a.action_var = action_var;
+    a.states = states;
+    a.actions = actions;
+    a.n = n;
+    a.inv_n = 1.0f;
+    a.clip_lo = 0.f;
+    a.clip_hi = 0.f;
+    a.seed_logp = grad_logprobs;
+    a.seed_val = grad_values;
+    a.seed_ent = grad_entropy;
+    const int rc = fwdbwd_dispatch(a, continuous, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+    return ppo_grad_reduce(state_dim, action_dim, workspace, workspace_bytes, grad_params_out, stream);
+}
+#else
 extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_dim, int continuous,
                                 float action_var, const float* states, const void* actions,
                                 const float* old_logprobs, const float* advantages,
@@ -846,12 +939,7 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
         action_dim > PPO_MAX_ACTION_DIM)
         return PPO_E_UNSUPPORTED;
     if (!workspace || workspace_bytes < update_ws_bytes(state_dim, action_dim)) return PPO_E_WORKSPACE;
-    FwdBwdArgs a;
-#ifdef PPO_PHASE_STAMPS
-    a.stamps = g_stamp_buf;
-#else
-    a.stamps = nullptr;
-#endif
+    FwdBwdArgs a{};
     a.params = params;
     a.S = state_dim;
     a.A = action_dim;
@@ -870,41 +958,7 @@ extern "C" int ppo_epoch_fwdbwd(const float* params, int state_dim, int action_d
     a.out_val = out_values;
     a.out_ent = out_entropy;
     a.out_surr = out_surrogate;
-    a.stride_actor = stride_of(n_actor_params(state_dim, action_dim));
-    a.stride_critic = stride_of(n_critic_params(state_dim));
-    a.ws_header = (int*)workspace;
-    a.partial_actor = (float*)((char*)workspace + FB_WS_HEADER);
-    // Symmetric-wave kernel (update_sym.hip) where selected, in the library variant that carries it; the
-    // forward/backward-pair kernel below otherwise.  PPO_FWDBWD=pair / sym forces one of them there
-    // (cross-checks, A/B timing).
-#ifdef PPO_WITH_SYM   // the library variant that carries update_sym.hip (never the product's default)
-    static const char* mode = getenv("PPO_FWDBWD");
-    bool sym = fwdbwd_sym_default(state_dim, action_dim, n_local);
-    if (mode && !strcmp(mode, "pair")) sym = false;
-    if (mode && !strcmp(mode, "sym")) sym = fwdbwd_sym_supported(state_dim, action_dim);
-    if (sym) {
-        role_wgs(action_dim, n_local, 16, 8, a.n_actor_wg, a.n_critic_wg);
-        a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
-        return launch_fwdbwd_sym(a, continuous, (hipStream_t)stream);
-    }
-#endif
-    role_wgs(action_dim, n_local, TILE_M, FB_PAIRS, a.n_actor_wg, a.n_critic_wg);
-    a.partial_critic = (float*)((char*)workspace + ws_critic_offset(state_dim, action_dim));
-    hipStream_t st = (hipStream_t)stream;
-    const int l1 = state_dim + 1 <= 16 ? 0 : (state_dim + 1 <= 32 ? 1 : 2);
-    const int amax = action_dim <= 2 ? 2 : (action_dim <= 4 ? 4 : 8);
-#define FB_DISPATCH_L1(C, AM)                                                            \
-    if (l1 == 0) return launch_fwdbwd<C, AM, 0>(a, st);                                  \
-    if (l1 == 1) return launch_fwdbwd<C, AM, 1>(a, st);                                  \
-    return launch_fwdbwd<C, AM, 2>(a, st);
-#define FB_DISPATCH(C)                                                                   \
-    if (amax == 2) { FB_DISPATCH_L1(C, 2) }                                              \
-    if (amax == 4) { FB_DISPATCH_L1(C, 4) }                                              \
-    FB_DISPATCH_L1(C, 8)
-    if (continuous) { FB_DISPATCH(true) }
-    FB_DISPATCH(false)
-#undef FB_DISPATCH
-#undef FB_DISPATCH_L1
+    return fwdbwd_dispatch(a, continuous, workspace, (hipStream_t)stream);
 }
 
 extern "C" int ppo_grad_reduce(int state_dim, int action_dim, const void* workspace,
@@ -1057,7 +1111,7 @@ extern "C" int ppo_update_epochs(float* params, int state_dim, int action_dim, i
     return 0;
 }
 
-extern "C" int ppo_hip_abi_version(void) { return 7; }
+extern "C" int ppo_hip_abi_version(void) { return 8; }
 
 extern "C" const char* ppo_hip_strerror(int code) {
     switch (code) {
@@ -1069,3 +1123,4 @@ extern "C" const char* ppo_hip_strerror(int code) {
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ppo_hip: unknown error";
     }
 }
+#endif  // PPO_FWDBWD_SEEDED

@@ -22,6 +22,12 @@ struct FwdBwdArgs {
     float* out_val;
     float* out_ent;
     float* out_surr;
+    // Seeded form only (update_vjp.hip: the vector-Jacobian product of evaluate()): the caller's
+    // gradients w.r.t. log-prob, value and entropy per sample, each may be null (= zeros); they
+    // replace the PPO loss's own seeds.
+    const float* seed_logp;
+    const float* seed_val;
+    const float* seed_ent;
     float* partial_actor;   // [n_actor_wg][stride_actor]
     float* partial_critic;  // [FB_GRID - n_actor_wg][stride_critic]
     int n_actor_wg;         // workgroups 0 .. n_actor_wg-1 train the actor, the rest the critic
@@ -50,10 +56,14 @@ __device__ __forceinline__ HeadIn<HEAD, AOUT> load_head_inputs(const FwdBwdArgs&
     HeadIn<HEAD, AOUT> in;
     in.ret = 0.f; in.old_lp = 0.f; in.adv = 0.f; in.action = 0;
     if constexpr (HEAD == HEAD_VALUE) {
+#ifndef PPO_FWDBWD_SEEDED   // (the seeded form has no returns / old log-probs / advantages)
         in.ret = valid ? a.ret[m] : 0.f;
+#endif
     } else {
+#ifndef PPO_FWDBWD_SEEDED
         in.old_lp = valid ? a.old_logp[m] : 0.f;
         in.adv = valid ? a.adv[m] : 0.f;
+#endif
         if constexpr (HEAD == HEAD_CATEGORICAL) {
             in.action = valid ? reinterpret_cast<const int*>(a.actions)[m] : 0;
         } else {
@@ -74,7 +84,11 @@ __device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const
         // 0.5 * MseLoss(state_values, rewards), PPO.py:240; d/dV of its mean = (V - R)/n
         const float R = in.ret;
         const float diff = o[0] - R;
+#ifdef PPO_FWDBWD_SEEDED
+        dout[0] = (valid && a.seed_val) ? a.seed_val[m] : 0.f;
+#else
         dout[0] = valid ? diff * a.inv_n : 0.f;
+#endif
         if (valid && writer) {
             loss_acc += (double)diff * (double)diff;
             if (a.out_val) a.out_val[m] = o[0];
@@ -107,8 +121,14 @@ __device__ __forceinline__ void head_loss_grad(const FwdBwdArgs& a, int A, const
         // unclipped branch is the smaller one.
         const bool inside = ratio >= a.clip_lo && ratio <= a.clip_hi;
         const bool gate = inside || (adv >= 0.f ? ratio <= a.clip_hi : ratio >= a.clip_lo);
+#ifdef PPO_FWDBWD_SEEDED
+        const float dlogp = (valid && a.seed_logp) ? a.seed_logp[m] : 0.f;
+        const float dent = (valid && a.seed_ent) ? a.seed_ent[m] : 0.f;
+        (void)gate;
+#else
         const float dlogp = (valid && gate) ? -(adv * ratio) * a.inv_n : 0.f;
         const float dent = valid ? -0.01f * a.inv_n : 0.f;
+#endif
         if constexpr (HEAD == HEAD_CATEGORICAL) {
             float pa = cat.pass[0], wq = 0.f;
 #pragma unroll

@@ -310,7 +310,7 @@ class ActorCritic(nn.Module):
             # through .data would not): an in-place write through any of the 12 tensors moves
             # flat._version, which the single-state session checks before every step
             mod_path, attr = key.rsplit(".", 1)
-            setattr(self.get_submodule(mod_path), attr, nn.Parameter(view, requires_grad=False))
+            setattr(self.get_submodule(mod_path), attr, nn.Parameter(view, requires_grad=True))
             off += n
         assert off == total
         self.flat = flat
@@ -380,8 +380,11 @@ class ActorCritic(nn.Module):
         return act.to(torch.int64), logp, val.reshape(-1, 1)
 
     def evaluate(self, state, action):
-        """ActorCritic.evaluate forward (PPO.py:102-121) -> (logprobs [T], values [T,1], entropy [T]).
-        Plain tensors: the backward pass lives in the fused update kernel, not in autograd."""
+        """ActorCritic.evaluate (PPO.py:102-121) -> (logprobs [T], values [T,1], entropy [T]).
+        With autograd on and parameters that require grad (the default, as in the reference) the three
+        outputs carry history w.r.t. the 12 parameters: a caller's own loss.backward() (PPO.py:244) fills
+        their .grad through ppo_evaluate_backward.  Under torch.no_grad() they are plain tensors.
+        PPO.update() does not come through here: its backward lives in the fused update kernel."""
         _require_gpu()
         x = torch.as_tensor(state, dtype=torch.float32, device=device).reshape(-1, self.state_dim).contiguous()
         n = x.shape[0]
@@ -389,6 +392,13 @@ class ActorCritic(nn.Module):
             a = torch.as_tensor(action, dtype=torch.float32, device=device).reshape(n, self.action_dim).contiguous()
         else:
             a = torch.as_tensor(action, device=device).reshape(n).to(torch.int32).contiguous()
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _EvaluateFn.apply(self, x.detach(), a.detach(), *params)
+        return self._evaluate_forward(x, a)
+
+    def _evaluate_forward(self, x, a):
+        n = x.shape[0]
         logp = torch.empty((n,), dtype=torch.float32, device=device)
         val = torch.empty((n,), dtype=torch.float32, device=device)
         ent = torch.empty((n,), dtype=torch.float32, device=device)
@@ -397,6 +407,53 @@ class ActorCritic(nn.Module):
                                            x.data_ptr(), a.data_ptr(), n, logp.data_ptr(),
                                            val.data_ptr(), ent.data_ptr(), _lib.stream_ptr()))
         return logp, val.reshape(-1, 1), ent
+
+    def _evaluate_backward(self, x, a, g_logp, g_val, g_ent, var32):
+        """dL/dparams (flat [P]) from dL/dlogprob, dL/dvalue, dL/dentropy (each [T] or None)."""
+        L = _lib.lib()
+        n = x.shape[0]
+        P = self.flat.numel()
+        need = L.ppo_workspace_bytes(self.state_dim, self.action_dim, n)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        grad = torch.empty(P + 2, dtype=torch.float32, device=device)
+        prep = lambda g: None if g is None else g.to(torch.float32).reshape(-1).contiguous()
+        gl, gv, ge = prep(g_logp), prep(g_val), prep(g_ent)
+        _lib.check(L.ppo_evaluate_backward(self.flat.data_ptr(), self.state_dim, self.action_dim,
+                                           int(self.has_continuous_action_space), var32, x.data_ptr(),
+                                           a.data_ptr(), n, _lib.ptr(gl), _lib.ptr(gv), _lib.ptr(ge),
+                                           grad.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return grad[:P]
+
+
+class _EvaluateFn(torch.autograd.Function):
+    """evaluate() as an autograd node: forward = ppo_evaluate, backward = ppo_evaluate_backward (the
+    fused forward/backward kernel seeded with the incoming gradients).  Gradients flow to the 12
+    parameters only (the reference never differentiates w.r.t. states or actions either)."""
+
+    @staticmethod
+    def forward(ctx, module, x, a, *params):
+        ctx.module = module
+        ctx.version = module.flat._version
+        ctx.var32 = module._var32()
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(x, a)
+        return module._evaluate_forward(x, a)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_logp, g_val, g_ent):
+        module = ctx.module
+        if module.flat._version != ctx.version:
+            raise RuntimeError("ppo_amd: the parameters were modified in place between evaluate() and backward(); "
+                               "the backward pass recomputes the forward from the parameters")
+        x, a = ctx.saved_tensors
+        flat_grad = module._evaluate_backward(x, a, g_logp, g_val, g_ent, ctx.var32)
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            k = int(np.prod(shp))
+            grads.append(flat_grad[off:off + k].view(shp))
+            off += k
+        return (None, None, None, *grads)
 
 
 class FusedAdam:

@@ -397,6 +397,121 @@ def test_single_launch_flat_scan_equals_three_launch_form(eng, tmp_path):
         assert np.array_equal(mom, z[f"m{i}"]), i
 
 
+def _torch_reference_model(P, S, A, cont, std):
+    """The reference's ActorCritic in plain PyTorch on the CPU (PPO.py:49-73, 102-121), with the given
+    weights: the fp32 reference the autograd path is compared with."""
+    import torch.nn as nn
+    from torch.distributions import Categorical, MultivariateNormal
+    head = nn.Tanh() if cont else nn.Softmax(dim=-1)
+    actor = nn.Sequential(nn.Linear(S, 64), nn.Tanh(), nn.Linear(64, 64), nn.Tanh(), nn.Linear(64, A), head)
+    critic = nn.Sequential(nn.Linear(S, 64), nn.Tanh(), nn.Linear(64, 64), nn.Tanh(), nn.Linear(64, 1))
+    model = nn.ModuleDict({"actor": actor, "critic": critic})
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in P.items()})
+
+    def evaluate(state, action):
+        if cont:
+            mean = actor(state)
+            var = torch.full((A,), std * std).expand_as(mean)
+            dist = MultivariateNormal(mean, torch.diag_embed(var))
+            if A == 1:
+                action = action.reshape(-1, A)
+        else:
+            dist = Categorical(actor(state))
+        return dist.log_prob(action), critic(state), dist.entropy()
+
+    return model, evaluate
+
+
+@pytest.mark.parametrize("S,A,cont,T", [(4, 2, False, 1000), (8, 4, False, 333), (24, 4, True, 2049), (26, 6, True, 700),
+                                        (40, 3, False, 500)])
+def test_evaluate_is_differentiable_like_the_reference(eng, S, A, cont, T):
+    """policy.evaluate() carries autograd history w.r.t. the 12 parameters, as the reference's does
+    (PPO.py:102-121 + PPO.py:244): for a loss built from all three outputs with random per-sample
+    weights, .grad of every parameter equals plain PyTorch's on the same model (1e-4 of the tensor's
+    largest entry), a second backward accumulates, and no_grad() gives plain tensors."""
+    ppo, _ = eng
+    rng = np.random.default_rng(S * 100 + A)
+    std = 0.5
+    P = {k: (rng.standard_normal(s) * (0.3 if k.endswith("weight") else 0.1)).astype(np.float32)
+         for k, s in O.param_shapes(S, A).items()}
+    x = rng.standard_normal((T, S)).astype(np.float32)
+    acts = rng.standard_normal((T, A)).astype(np.float32) if cont else rng.integers(0, A, T)
+    w = [rng.standard_normal(T).astype(np.float32) for _ in range(3)]
+    model, ref_eval = _torch_reference_model(P, S, A, cont, std)
+    lp, v, ent = ref_eval(torch.from_numpy(x), torch.from_numpy(acts))
+    loss_ref = (torch.from_numpy(w[0]) * lp + torch.from_numpy(w[1]) * v.squeeze(-1) ** 2 + torch.from_numpy(w[2]) * ent).sum()
+    loss_ref.backward()
+    want = {k: p.grad.numpy() for k, p in model.named_parameters()}
+
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 1, 0.2, cont, std if cont else None)
+    agent.policy.load_state_dict({k: torch.from_numpy(val) for k, val in P.items()})
+    pol = agent.policy
+    assert all(p.requires_grad for p in pol.parameters())
+    dev = lambda a: torch.from_numpy(a).cuda()
+    lp_g, v_g, ent_g = pol.evaluate(dev(x), dev(acts))
+    assert lp_g.requires_grad and v_g.shape == (T, 1)
+    assert rel_err(lp_g.detach().cpu().numpy(), lp.detach().numpy()) < TOL_REL
+    loss = (dev(w[0]) * lp_g + dev(w[1]) * v_g.squeeze(-1) ** 2 + dev(w[2]) * ent_g).sum()
+    assert rel_err(np.array([loss.item()]), np.array([loss_ref.item()])) < 1e-4
+    loss.backward()
+    for k, p in pol.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        assert max_abs(p.grad.cpu().numpy(), want[k]) < 1e-4 * max(float(np.abs(want[k]).max()), 1e-30), k
+    first = {k: p.grad.clone() for k, p in pol.named_parameters()}
+    lp_g, v_g, ent_g = pol.evaluate(dev(x), dev(acts))
+    (dev(w[0]) * lp_g).sum().backward()                      # only one output used: the others' seeds are zeros
+    lp2, _, _ = ref_eval(torch.from_numpy(x), torch.from_numpy(acts))
+    model.zero_grad()
+    (torch.from_numpy(w[0]) * lp2).sum().backward()
+    for k, p in pol.named_parameters():
+        acc = p.grad - first[k]
+        ref_g = dict(model.named_parameters())[k].grad
+        ref_g = np.zeros(p.shape, np.float32) if ref_g is None else ref_g.numpy()
+        scale = max(float(np.abs(want[k]).max()), 1e-30)
+        assert max_abs(acc.cpu().numpy(), ref_g) < 2e-4 * scale, k
+    with torch.no_grad():
+        assert not pol.evaluate(dev(x), dev(acts))[0].requires_grad
+    # a write to the parameters between evaluate() and backward() is refused, as autograd refuses it
+    lp_g, _, _ = pol.evaluate(dev(x), dev(acts))
+    with torch.no_grad():
+        pol.actor[0].bias.add_(1.0)
+    with pytest.raises(RuntimeError):
+        lp_g.sum().backward()
+
+
+def test_reference_update_loop_written_with_autograd_matches_fused_update(eng):
+    """The K-epoch loop of PPO.py:224-245 written out by a caller - policy.evaluate, the clipped loss,
+    loss.mean().backward(), torch.optim.Adam over the two parameter groups - on this engine's
+    ActorCritic gives the parameters the fused update() gives (both compute PPO.py:227-245)."""
+    ppo, _ = eng
+    d = load_case("c2_lunarlander")
+    K = 4
+    fused = agent_from_case(ppo, d, K)
+    fused.update()
+    agent = agent_from_case(ppo, d, K)
+    pol = agent.policy
+    opt = torch.optim.Adam([{"params": pol.actor.parameters(), "lr": float(d["lr_actor"])},
+                            {"params": pol.critic.parameters(), "lr": float(d["lr_critic"])}])
+    dev = lambda a, dt=torch.float32: torch.from_numpy(np.asarray(a)).to("cuda", dt)
+    states, actions = dev(d["states"]), dev(d["actions"], torch.int64)
+    old_lp, rewards = dev(d["old_logprobs"]), dev(d["returns_norm"])
+    adv = dev(d["advantages"])
+    mse = torch.nn.MSELoss()
+    for _ in range(K):
+        logprobs, state_values, dist_entropy = pol.evaluate(states, actions)
+        state_values = torch.squeeze(state_values)
+        ratios = torch.exp(logprobs - old_lp.detach())
+        surr1 = ratios * adv
+        surr2 = torch.clamp(ratios, 1 - 0.2, 1 + 0.2) * adv
+        loss = -torch.min(surr1, surr2) + 0.5 * mse(state_values, rewards) - 0.01 * dist_entropy
+        opt.zero_grad()
+        loss.mean().backward()
+        opt.step()
+    torch.cuda.synchronize()
+    assert max_abs(pol.flat.cpu().numpy(), fused.policy.flat.cpu().numpy()) < 2e-5
+    assert max_abs(pol.flat.cpu().numpy(), np.concatenate([d[f"K{K}/param/{k}"].reshape(-1) for k in O.PARAM_KEYS])) < TOL_PARAM
+
+
 # ------------------------------------------------------------------------------ update
 def agent_from_case(ppo, d, K):
     cont = bool(d["continuous"])
@@ -853,8 +968,9 @@ def test_checkpoint_roundtrip(eng, tmp_path):
     agent.load(os.path.join(GOLDEN, "ckpt_CartPole-v1.pth"))      # written by the reference's save()
     env = "CartPole-v1"
     lp, v, ent = agent.policy_old.evaluate(d[f"{env}/states"], d[f"{env}/actions"])
-    assert rel_err(lp.cpu().numpy(), d[f"{env}/logprobs"]) < TOL_REL
-    assert rel_err(v.cpu().numpy().reshape(-1), d[f"{env}/critic_out"]) < TOL_REL
+    assert lp.requires_grad and v.requires_grad           # as the reference's evaluate(): differentiable
+    assert rel_err(lp.detach().cpu().numpy(), d[f"{env}/logprobs"]) < TOL_REL
+    assert rel_err(v.detach().cpu().numpy().reshape(-1), d[f"{env}/critic_out"]) < TOL_REL
     out = tmp_path / "x.pth"
     agent.save(str(out))
     sd = torch.load(str(out))
