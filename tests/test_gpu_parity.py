@@ -960,6 +960,33 @@ def test_two_rank_update_equals_single_buffer(eng, case):
     assert rel_err(res[0][2], d[f"K{K}/loss_mean_all"]) < 1e-4
 
 
+def test_bench_two_rank_line_is_self_checking(eng):
+    """bench.py launched as the driver launches it for N > 1 (torch.distributed.run, one rank per
+    process; here two ranks share this GPU over gloo): rank 0 prints ONE JSON line whose `distributed`
+    entry records the backend, the world size, the all-reduce time, and that parameters and loss are
+    bit-identical on every rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29300 + os.getpid() % 500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--k-epochs", "3", "--n-envs", "256", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=dict(os.environ, PPO_BENCH_BACKEND="gloo", PPO_BENCH_WATCHDOG="100"),
+                       capture_output=True, text=True, timeout=170, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and abs(out["value"] - 2 * 256 * 128 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    dist = out["distributed"]
+    assert dist["backend"] == "gloo" and dist["world_size"] == 2
+    assert dist["replica_check"]["replicas_identical"] is True
+    assert dist["allreduce_us_per_epoch"] > 0 and dist["allreduce_bytes"] == 4 * (9155 + 2)
+    assert out["roofline"]["launches_timed"] == 3 and "other_configs" not in out
+
+
 # ------------------------------------------------------------------------------ checkpoints / schedule
 def test_checkpoint_roundtrip(eng, tmp_path):
     ppo, _lib = eng
