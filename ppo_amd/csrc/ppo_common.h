@@ -488,8 +488,9 @@ template <> struct TileNet<16> {
 
 // ------------------------------------------------------------------ heads
 // The head functions below switch floating-point contraction off: every multiply and add is
-// rounded as written, so the same (state, action) gives bit-identical log-probs in every kernel
-// that inlines them (per-step act, fused rollout, evaluate, update), whatever the surrounding code.
+// rounded as written, so the same pre-head outputs give bit-identical log-probs in every kernel that
+// inlines them, whatever the surrounding code (act, rollout and evaluate kernels also form those
+// outputs in one order, out_layer_act; the update kernels' out_layer sums in another: equal to rounding).
 // exp / log / divide of the distribution heads.  The heads are one dependent chain per sample (no
 // instruction-level parallelism to hide latencies), so they use the hardware's base-2 exp / log and
 // reciprocal (<= 1 ulp each) instead of the ~10-instruction correctly rounded library sequences;
