@@ -379,8 +379,12 @@ def main():
         for key, steps, warmup in OTHER_CONFIGS:
             c = dict(CONFIGS[key])
             c["name"] = c["name"].format(**c)
-            o = measure(key, c, steps, warmup, 1, 0, False, with_cpu=not args.no_cpu_baseline,
-                        cpu_threads=args.cpu_threads)
+            try:        # an extra must never cost the headline line
+                o = measure(key, c, steps, warmup, 1, 0, False, with_cpu=not args.no_cpu_baseline,
+                            cpu_threads=args.cpu_threads)
+            except Exception as e:   # noqa: BLE001
+                others[key] = {"workload": c["name"], "error": f"{type(e).__name__}: {e}"}
+                continue
             others[key] = {"workload": c["name"], "value": o["value"], "unit": o["unit"], "steps": steps,
                            "warmup": warmup, "ms_per_step": o["ms_per_step"],
                            "roofline_frac": o["roofline"]["frac"],
