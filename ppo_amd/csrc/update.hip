@@ -119,7 +119,12 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     constexpr bool L3_VALU = AOUT <= 2;  // output-layer wgrad on the VALU (A*32 FMAs per tile)
     constexpr int KS1MAX = L1 == 0 ? 8 : (L1 == 1 ? 16 : 32);
 
+    // Output-layer wgrad on the MFMA (AOUT > 2): 32x32x2 tiles for AOUT = 4, 16x16x4 tiles for AOUT = 8
+    // (half the matrix time; measured -2 % per epoch at 6 continuous actions with the role split
+    // retuned, but +2 % at 4 discrete ones, hence the two forms)
+    constexpr bool L3_NARROW = AOUT > 4;
     f32x16 gW3[2], gb2[2], gW3v[L3_VALU ? AOUT : 1][2];
+    f32x4 gW3n[4];   // L3_NARROW: tile t covers units 16t .. 16t+15, rows = outputs
     float gb3[AOUT];
     double loss_acc = 0.0;
     STAMP_DECL
@@ -132,6 +137,8 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     }
 #pragma unroll
     for (int k = 0; k < AOUT; ++k) gb3[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gW3n[i] = 0.f;
 
     // xf[s] = X_aug[this lane's sample][input 2s+h] (1 at input S, 0 beyond), fetched one tile
     // ahead.  Row pointer + constant offsets: one instruction per load.
@@ -203,8 +210,8 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
 
         float* const hrow = h1s + c * W2_LD + 4 * h;
         if constexpr (!L3_VALU) {
-            // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u]; k-step s of
-            // half-wave h is sample 16h + s.  H2 passes through h1s before H1 takes its place.
+            // output-layer wgrad on the MFMA: dW3[a, u] += sum_m dout[m, a] H2[m, u]; A[i = output][k =
+            // sample], B[k = sample][j = unit].  H2 passes through h1s before H1 takes its place.
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -218,16 +225,30 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
 #pragma unroll
                 for (int k = 0; k < AOUT; ++k) dtu[k * DT_LD + c] = dout[k];
             }
-            const float* arow = dtu + min(c, AOUT) * DT_LD + 16 * h;  // row AOUT is zero
-            const float* bcol = h1s + (16 * h) * W2_LD + c;
+            if constexpr (L3_NARROW) {
+                const int c16 = lane & 15, q4 = lane >> 4;
+                const float* arow = dtu + min(c16, AOUT) * DT_LD + q4;          // row AOUT is zero; + 4 s
+                const float* bcol = h1s + q4 * W2_LD + c16;                       // + 4 s rows, + 16 t columns
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 4 * g);
+                for (int s = 0; s < 8; ++s) {
+                    const float av = arow[4 * s];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int sm = 4 * g + j;
-                    gW3[0] = mfma32(av[j], bcol[sm * W2_LD], gW3[0]);
-                    gW3[1] = mfma32(av[j], bcol[sm * W2_LD + 32], gW3[1]);
+                    for (int t4 = 0; t4 < 4; ++t4)
+                        gW3n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcol[4 * s * W2_LD + 16 * t4], gW3n[t4], 0, 0, 0);
+                }
+            } else {
+                // k-step s of half-wave h is sample 16h + s
+                const float* arow = dtu + min(c, AOUT) * DT_LD + 16 * h;  // row AOUT is zero
+                const float* bcol = h1s + (16 * h) * W2_LD + c;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int sm = 4 * g + j;
+                        gW3[0] = mfma32(av[j], bcol[sm * W2_LD], gW3[0]);
+                        gW3[1] = mfma32(av[j], bcol[sm * W2_LD + 32], gW3[1]);
+                    }
                 }
             }
         }
@@ -315,13 +336,24 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         for (int k = 0; k < AOUT; ++k)
             if (k < A) RED_PUT(o_w3 + k * HID + lane, dw3_u[k]);
     } else {
+        if constexpr (L3_NARROW) {
+            // C/D of the 16x16x4 tile: column (unit) = lane & 15, row (output) = 4 * (lane >> 4) + reg
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int act_row = rho(r, h);
-                if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int act_row = 4 * (lane >> 4) + r;
+                    if (act_row < A) RED_PUT(o_w3 + act_row * HID + 16 * t4 + (lane & 15), gW3n[t4][r]);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int act_row = rho(r, h);
+                    if (act_row < A) RED_PUT(o_w3 + act_row * HID + 32 * j + c, gW3[j][r]);
+                }
+        }
     }
     if (lane == 0) {
 #pragma unroll
@@ -768,10 +800,10 @@ static inline int stride_of(int n) { return (n + 1 + 63) / 64 * 64; }
 
 // Workgroups per role.  The actor's tiles cost more than the critic's (wider output layer, the
 // distribution head, for more than two outputs an extra MFMA weight gradient): measured ratios r
-// of per-tile time are 1.12 (2 discrete actions) and 1.37 (6 continuous).  Every pair of a role
+// of per-tile time are 1.12 (2 discrete actions), 1.25 (4) and 1.31 (6 continuous).  Every pair of a role
 // runs ceil(tiles / pairs) tiles, so the split minimises max(actor iterations * r, critic
 // iterations); at 524 288 samples that is 135 : 121 (31 and 34 iterations: 273.5 us per launch against
-// 275.8 for 138 : 118 = 30 and 35 iterations, same-box sweep), at 8.4 M samples 148 : 108.
+// 275.8 for 138 : 118 = 30 and 35 iterations, same-box sweep), at 8.4 M samples of 6 actions 145 : 111.
 // The fwd/bwd kernel leaves the split in the workspace header for the reduction kernels.
 #define FB_MAX_ROLE_WGS (3 * FB_GRID / 4)
 #define FB_WS_HEADER 256
@@ -783,7 +815,7 @@ static void role_wgs(int A, int64_t n, int tile, int slots, int& n_actor, int& n
     if (tune && atoi(tune) >= FB_GRID - FB_MAX_ROLE_WGS && atoi(tune) <= FB_MAX_ROLE_WGS) {
         best = atoi(tune);
     } else {
-        const double r = 1.0 + (A > 2 ? 0.062 : 0.06) * A;
+        const double r = 1.0 + (A > 4 ? 0.051 : (A > 2 ? 0.062 : 0.06)) * A;
         double best_cost = 1e300;
         for (int na = FB_GRID - FB_MAX_ROLE_WGS; na <= FB_MAX_ROLE_WGS; ++na) {
             const int64_t ia = (tiles + slots * na - 1) / (slots * na);

@@ -48,7 +48,7 @@ fwd_names = ["L1 + tanh", "L2 + tanh", "out layer + head + L3 wgrad", "WAIT barr
 bwd_names = ["x loads issue", "WAIT barrier (release)", "deferred wgrad1 + WAIT barrier (written)", "dgrad",
              "dZ1", "wgrad2", "dZ1 store (+ wgrad1 if S >= 32)", "epilogue"]
 def actor_wgs(A, n):                                  # actor_wgs() of update.hip
-    r = 1.0 + (0.062 if A > 2 else 0.06) * A
+    r = 1.0 + (0.051 if A > 4 else (0.062 if A > 2 else 0.06)) * A
     tiles = (n + 31) // 32
     best, best_cost = 128, 1e300
     for na in range(64, 193):
