@@ -179,12 +179,12 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             // next tile's observations: right away for narrow inputs; for S >= 32 (32 registers) only at
             // the end of the iteration, when the activations are dead
             if constexpr (L1 < 2) load_xf(min(tile + ctx.tstride, ctx.n_tiles - 1) * TILE_M, half_s);
-            H1[0] = tanh16_prescaled(z0);
-            H1[1] = tanh16_prescaled(z1);
+            H1[0] = L1 == 0 ? tanh16_prescaled_pk(z0) : tanh16_prescaled(z0);
+            H1[1] = L1 == 0 ? tanh16_prescaled_pk(z1) : tanh16_prescaled(z1);
         }
         STAMP(0)
         // ---------------- layer 2
-        mlp_layer2(L, c, h, H1, H2);
+        mlp_layer2<L1 == 0>(L, c, h, H1, H2);
         STAMP(1)
         float o[AOUT];
         out_layer<AOUT>(L, A, H2, h, o);
@@ -556,9 +556,14 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             const f32x4 h0 = *reinterpret_cast<const f32x4*>(hrow + 8 * q);
             const f32x4 h1 = *reinterpret_cast<const f32x4*>(hrow + 32 + 8 * q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                d0[4 * q + j] *= 1.0f - h0[j] * h0[j];
-                d1[4 * q + j] *= 1.0f - h1[j] * h1[j];
+            for (int j = 0; j < 4; j += 2) {   // on register pairs (v_pk_fma_f32 / v_pk_mul_f32)
+                const f32x2 one = {1.0f, 1.0f};
+                const f32x2 a = {h0[j], h0[j + 1]}, b = {h1[j], h1[j + 1]};
+                const f32x2 ta = __builtin_elementwise_fma(-a, a, one), tb = __builtin_elementwise_fma(-b, b, one);
+                const f32x2 da = (f32x2){d0[4 * q + j], d0[4 * q + j + 1]} * ta;
+                const f32x2 db = (f32x2){d1[4 * q + j], d1[4 * q + j + 1]} * tb;
+                d0[4 * q + j] = da.x; d0[4 * q + j + 1] = da.y;
+                d1[4 * q + j] = db.x; d1[4 * q + j + 1] = db.y;
             }
         }
         STAMP(4)
