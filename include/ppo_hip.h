@@ -218,6 +218,17 @@ int ppo_act_session_step(ppo_act_session* session, const float* params, uint64_t
                          float action_var, const float* host_state, uint64_t seed, uint64_t rng_offset, float* state_row,
                          void* action_row, float* logprob_row, float* value_row, void* action_out,
                          void* after_stream);
+/* The same step with its unchanging arguments bound beforehand (a host loop's per-step cost is mostly
+ * argument marshalling in the binding).  _bind stores the weights, their version, the variance, the
+ * host state / action buffers, the seed, the four buffer columns (dense rows: state_dim floats; one
+ * int32 or action_dim floats; one float; one float) and the stream the first kernel after a drain is
+ * ordered behind; _step_bound(row, rng_offset) is ppo_act_session_step on row `row` of those columns.
+ * Bind again whenever one of the bound things changes. */
+int ppo_act_session_bind(ppo_act_session* session, const float* params, uint64_t params_version,
+                         float action_var, const float* host_state, void* action_out, uint64_t seed,
+                         float* states, void* actions, float* logprobs, float* values,
+                         void* after_stream);
+int ppo_act_session_step_bound(ppo_act_session* session, int64_t row, uint64_t rng_offset);
 int ppo_act_session_drain(ppo_act_session* session);
 int ppo_act_session_destroy(ppo_act_session* session);
 

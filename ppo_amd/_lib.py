@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to before d
 HERE = os.path.dirname(os.path.abspath(__file__))
 # PPO_HIP_LIB: diagnostic builds of the same sources (python -m ppo_amd.build --variant ...)
 LIB_PATH = os.environ.get("PPO_HIP_LIB") or os.path.join(HERE, "libppo_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _SIGNATURES = {
     "ppo_hip_abi_version": (c_int, []),
@@ -48,6 +48,9 @@ _SIGNATURES = {
     "ppo_act_session_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "ppo_act_session_step": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_uint64, c_uint64, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppo_act_session_bind": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_void_p, c_uint64, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppo_act_session_step_bound": (c_int, [c_void_p, c_int64, c_uint64]),
     "ppo_act_session_drain": (c_int, [c_void_p]),
     "ppo_act_session_destroy": (c_int, [c_void_p]),
     "ppo_cartpole_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

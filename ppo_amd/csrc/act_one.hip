@@ -291,6 +291,20 @@ struct ppo_act_session {
     unsigned seen_unserved;
     int inflight;             // kernels launched and not yet known to have ended
     unsigned wait_ticks;
+    // ppo_act_session_bind: everything of a step that does not change from step to step
+    struct {
+        const float* params;
+        uint64_t version, seed;
+        float action_var;
+        const float* host_state;
+        void* action_out;
+        float* states;
+        char* actions;
+        float* logprobs;
+        float* values;
+        void* after_stream;
+        bool set;
+    } bound;
 };
 
 static int session_launch(ppo_act_session* s) {
@@ -415,4 +429,40 @@ extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, uin
     --s->inflight;                                     // the kernel that served k
     memcpy(action_out, mb->action, sizeof(float) * (s->continuous ? s->A : 1));
     return 0;
+}
+
+// The per-step call of a host loop costs mostly argument marshalling in the binding (twelve arguments
+// of ppo_act_session_step against three here), so the arguments that stay the same from step to step
+// are bound once: the weights and their version, the variance, the page-locked state / action
+// buffers, the seed and the four buffer columns (dense rows: state_dim floats, one int32 or
+// action_dim floats, one float, one float).  Bind again whenever one of them changes (new weights
+// or version, another variance, moved columns, another stream to order the first kernel behind).
+extern "C" int ppo_act_session_bind(ppo_act_session* s, const float* params, uint64_t params_version,
+                                    float action_var, const float* host_state, void* action_out,
+                                    uint64_t seed, float* states, void* actions, float* logprobs,
+                                    float* values, void* after_stream) {
+    if (!s || !params || !host_state || !action_out || !states || !actions || !logprobs || !values)
+        return PPO_E_BADARG;
+    s->bound.params = params;
+    s->bound.version = params_version;
+    s->bound.seed = seed;
+    s->bound.action_var = action_var;
+    s->bound.host_state = host_state;
+    s->bound.action_out = action_out;
+    s->bound.states = states;
+    s->bound.actions = (char*)actions;
+    s->bound.logprobs = logprobs;
+    s->bound.values = values;
+    s->bound.after_stream = after_stream;
+    s->bound.set = true;
+    return 0;
+}
+
+extern "C" int ppo_act_session_step_bound(ppo_act_session* s, int64_t row, uint64_t rng_offset) {
+    if (!s || !s->bound.set || row < 0) return PPO_E_BADARG;
+    const size_t action_bytes = sizeof(float) * (s->continuous ? (size_t)s->A : 1);   // int32 and float are 4 bytes
+    return ppo_act_session_step(s, s->bound.params, s->bound.version, s->bound.action_var, s->bound.host_state,
+                                s->bound.seed, rng_offset, s->bound.states + row * s->S,
+                                s->bound.actions + row * action_bytes, s->bound.logprobs + row,
+                                s->bound.values + row, s->bound.action_out, s->bound.after_stream);
 }

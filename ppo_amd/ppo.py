@@ -697,17 +697,30 @@ class PPO:
 
     def _make_session_step(self):
         """The per-step work of the session path as one closure over everything that does not change
-        between steps (this function is most of what a step costs on the host)."""
+        between steps (this function is most of what a step costs on the host).  Whatever stays the
+        same from step to step - weights and their version, variance, the page-locked buffers, the
+        buffer columns, the stream - is bound in the library (ppo_act_session_bind) and bound again
+        when it changes: the per-step call then carries three arguments instead of thirteen."""
         b, cnt, pol = self.buffer, self.buffer._count, self.policy_old
         state_np, act_np, act_int = self._pin_np
         state_ptr, act_ptr = self._pin_ptr[0], self._pin_ptr[1]
-        step, sess, seed = self._act_step_fn, self._act_session, self._rng_seed
+        L = _lib.lib()
+        bind, step, sess, seed = L.ppo_act_session_bind, L.ppo_act_session_step_bound, self._act_session, self._rng_seed
         flat = pol.flat
         params = flat.data_ptr()               # the flat vector is allocated once
         want_shape = (self.state_dim,)
         cont = self.has_continuous_action_space
         raw_stream = torch._C._cuda_getCurrentRawStream
         dev_index = device.index or 0
+        bound = [None, None, None, None]       # version, variance, the columns' address table, stream
+
+        def rebind(version, var, ra, stream):
+            for col, width in (("states", self.state_dim * 4), ("actions", (self.action_dim if cont else 1) * 4),
+                               ("logprobs", 4), ("state_values", 4)):
+                assert ra[col][1] == width, "the session addresses the buffer's columns as dense rows"
+            _lib.check(bind(sess, params, version, var, state_ptr, act_ptr, seed, ra["states"][0], ra["actions"][0],
+                            ra["logprobs"][0], ra["state_values"][0], stream))
+            bound[:] = [version, var, ra, stream]
 
         def host_step(state):
             if state.shape != want_shape:
@@ -718,15 +731,12 @@ class PPO:
                 b.reserve(lo + 1)
             cnt["states"] = cnt["actions"] = cnt["logprobs"] = cnt["state_values"] = lo + 1
             self._rng_offset = off = self._rng_offset + 1
-            ra = b._row_addr
-            ps, ss = ra["states"]
-            pa, sa = ra["actions"]
-            pl, sl = ra["logprobs"]
-            pv, sv = ra["state_values"]
             # flat._version counts the in-place writes to the weights (through any of their views): a
             # write since the waiting kernel was launched makes the library replace that kernel
-            rc = step(sess, params, flat._version, pol._var_host, state_ptr, seed, off, ps + lo * ss, pa + lo * sa,
-                      pl + lo * sl, pv + lo * sv, act_ptr, raw_stream(dev_index))
+            version, var, ra = flat._version, pol._var_host, b._row_addr
+            if version != bound[0] or var != bound[1] or ra is not bound[2]:
+                rebind(version, var, ra, raw_stream(dev_index))
+            rc = step(sess, lo, off)
             if rc:
                 _lib.check(rc)
             if cont:

@@ -68,14 +68,17 @@ agent.buffer.reserve(n + 64)
 x = np.random.default_rng(0).standard_normal(4)
 agent.select_action(x)
 agent._act_drain()
-real = agent._act_step_fn
-agent._act_step_fn = lambda *a: 0
+from ppo_amd import _lib
+L = _lib.lib()
+real = L.ppo_act_session_step_bound, L.ppo_act_session_bind
+L.ppo_act_session_step_bound = lambda *a: 0        # (instance attributes shadow the library's functions)
+L.ppo_act_session_bind = lambda *a: 0
 agent._host_step = agent._make_session_step()
 t0 = time.perf_counter()
 for _ in range(n):
     agent.select_action(x)
 dt_py = (time.perf_counter() - t0) / n
-agent._act_step_fn = real
+L.ppo_act_session_step_bound, L.ppo_act_session_bind = real
 agent._host_step = agent._make_session_step()
 agent.buffer.clear()
 print(f"of which the Python wrapper (no library call): {dt_py * 1e6:.1f} us")
