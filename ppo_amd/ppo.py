@@ -957,3 +957,31 @@ class PPO:
     def load(self, checkpoint_path):
         self.policy_old.load_state_dict(torch.load(checkpoint_path, map_location=lambda storage, loc: storage))
         self.policy.load_state_dict(torch.load(checkpoint_path, map_location=lambda storage, loc: storage))
+
+    # ------------------------------------------------------------------ resume (not in the reference)
+    # The reference's checkpoint holds policy_old's weights only (PPO.py:253-258): no optimizer state, no
+    # action_std, no sampling state, so a reloaded run is not the run that was saved.  save_resume /
+    # load_resume write and read everything update() and select_action() depend on, in a file of their
+    # own format (plain tensors and numbers; the reference-format file stays what save() writes).
+    def save_resume(self, checkpoint_path):
+        self._act_drain()
+        torch.save({"format": "ppo_amd.resume.v1",
+                    "policy": {k: v.detach().cpu().clone() for k, v in self.policy.state_dict().items()},
+                    "policy_old": {k: v.detach().cpu().clone() for k, v in self.policy_old.state_dict().items()},
+                    "optimizer": self.optimizer.state_dict(),
+                    "action_std": self.action_std if self.has_continuous_action_space else None,
+                    "rng_seed": self._rng_seed, "rng_offset": self._rng_offset}, checkpoint_path)
+
+    def load_resume(self, checkpoint_path):
+        ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        if ck.get("format") != "ppo_amd.resume.v1":
+            raise ValueError(f"{checkpoint_path} is not a resume checkpoint written by save_resume()")
+        self.policy.load_state_dict(ck["policy"])
+        self.policy_old.load_state_dict(ck["policy_old"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+        if self.has_continuous_action_space and ck["action_std"] is not None:
+            self.action_std = ck["action_std"]
+            self.policy.set_action_std(self.action_std)
+            self.policy_old.set_action_std(self.action_std)
+        self._rng_seed, self._rng_offset = ck["rng_seed"], ck["rng_offset"]
+        self._host_step = None     # a single-state session re-binds the seed on its next step

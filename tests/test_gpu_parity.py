@@ -644,6 +644,41 @@ def test_two_consecutive_updates_golden(eng, name):
         assert rel_err(agent.last_loss.cpu().numpy(), d[f"u{u}/loss_mean_all"]) < 1e-4
 
 
+def test_resume_checkpoint_continues_the_same_run(eng, tmp_path):
+    """update, save_resume, update  ==  (fresh agent) load_resume, update: parameters, Adam state and
+    losses bit for bit - the second update depends on the first one's Adam moments and step count,
+    which the reference's own checkpoint (policy_old only) does not carry."""
+    ppo, _ = eng
+    d = load_case("two_update_continuous")
+    cont, K, S, A = bool(d["continuous"]), int(d["K"]), int(d["S"]), int(d["A"])
+    make = lambda: ppo.PPO(S, A, float(d["lr_actor"]), float(d["lr_critic"]), float(d["gamma"]), K,
+                           float(d["eps_clip"]), cont, float(d["action_std"]))
+    load = lambda ag, u: ag.buffer.load_rollout(d[f"u{u}/states"], d[f"u{u}/actions"], d[f"u{u}/old_logprobs"],
+                                                d[f"u{u}/old_values"], d[f"u{u}/rewards"], d[f"u{u}/terminals"])
+    a = make()
+    sd = {k: torch.from_numpy(v) for k, v in case_params(d).items()}
+    a.policy.load_state_dict(sd)
+    a.policy_old.load_state_dict(sd)
+    load(a, 1)
+    a.update()
+    if float(d["u2/action_std"]) != a.action_std:
+        a.decay_action_std(0.05, 0.1)
+    a.save_resume(str(tmp_path / "r.pt"))
+    load(a, 2)
+    a.update()
+    b = make()
+    b.load_resume(str(tmp_path / "r.pt"))
+    assert b.action_std == float(d["u2/action_std"]) and b.optimizer.step_count == K
+    load(b, 2)
+    b.update()
+    torch.cuda.synchronize()
+    assert torch.equal(a.policy.flat, b.policy.flat) and torch.equal(a.policy_old.flat, b.policy_old.flat)
+    assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+    assert torch.equal(a.last_loss, b.last_loss) and b.optimizer.step_count == 2 * K
+    got = {k: v.cpu().numpy() for k, v in b.policy.state_dict().items()}
+    assert max(max_abs(got[k], d[f"u2/after/param/{k}"]) for k in O.PARAM_KEYS) < TOL_PARAM
+
+
 def test_update_deterministic(eng):
     ppo, _ = eng
     d = load_case("c2_lunarlander")

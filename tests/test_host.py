@@ -251,3 +251,39 @@ def test_public_header_is_plain_c(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
                         "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_resume_checkpoint_round_trip(tmp_path):
+    """save_resume / load_resume carry what the reference's checkpoint leaves out (PPO.py:253-258 saves
+    policy_old only): both policies, Adam's moments and step count, the learning rates, action_std and
+    the sampling stream's position.  No compute involved: runs without a GPU."""
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        from ppo_amd import ppo
+        a = ppo.PPO(11, 3, 3e-4, 1e-3, 0.99, 5, 0.2, True, 0.6)
+        b = ppo.PPO(11, 3, 1e-4, 2e-3, 0.99, 5, 0.2, True, 0.3)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        a.policy.flat.copy_(torch.randn(a.policy.flat.shape, generator=g))
+        a.policy_old.flat.copy_(torch.randn(a.policy.flat.shape, generator=g))
+        a.optimizer.exp_avg.copy_(torch.randn(a.policy.flat.shape, generator=g))
+        a.optimizer.exp_avg_sq.copy_(torch.rand(a.policy.flat.shape, generator=g))
+    a.optimizer.step_count = 123
+    with contextlib.redirect_stdout(io.StringIO()):
+        a.decay_action_std(0.05, 0.1)
+    a._rng_seed, a._rng_offset = 987654321, 4242
+    path = tmp_path / "resume.pt"
+    a.save_resume(str(path))
+    b.load_resume(str(path))
+    assert torch.equal(b.policy.flat.cpu(), a.policy.flat.cpu()) and torch.equal(b.policy_old.flat.cpu(), a.policy_old.flat.cpu())
+    assert torch.equal(b.optimizer.exp_avg.cpu(), a.optimizer.exp_avg.cpu())
+    assert torch.equal(b.optimizer.exp_avg_sq.cpu(), a.optimizer.exp_avg_sq.cpu())
+    assert b.optimizer.step_count == 123 and [g_["lr"] for g_ in b.optimizer.param_groups] == [3e-4, 1e-3]
+    assert b.action_std == a.action_std == 0.55 and b.policy_old._var_host == a.policy_old._var_host
+    assert (b._rng_seed, b._rng_offset) == (987654321, 4242)
+    # the reference-format file is untouched by all this: 12 tensors of policy_old
+    a.save(str(tmp_path / "ref.pth"))
+    assert len(torch.load(str(tmp_path / "ref.pth"))) == 12
+    with pytest.raises(ValueError):
+        b.load_resume(str(tmp_path / "ref.pth"))
