@@ -51,6 +51,21 @@
 #define STG_MAT (TILE_M * W2_LD)
 #define STG_PAIR_FLOATS (2 * STG_MAT + 9 * DT_LD)   // (+ STG_MAT for the private dZ1 buffer when S <= 31)
 #define CS_LD 65                                       // row stride of colsum()'s scratch: odd => conflict-free
+// 16x16x4 weight-gradient tiles read their operands column-wise from the [sample][unit] rows: k-step s of
+// lane group q4 = lane >> 4 is sample NARROW_S(s) + NARROW_Q(q4).  A 4-byte LDS read services lane
+// groups {0, 1} and {2, 3} together (32 lanes each, banks = dword address mod 32): their rows are 4
+// apart, i.e. 4 * W2_LD = 16 banks apart, and each reads 16 consecutive columns, so the access is
+// conflict-free (rows 1 apart, the plain 4s + q4 order, overlap in 12 of 16 banks: 2 LDS cycles more
+// per read).  One k-step's four rows {o, o+1, o+4, o+5} stay within 6 rows, so that the matching global
+// loads of narrow observations touch one cache line as they do in the plain order.
+#define NARROW_S(s) (2 * ((s) & 1) + 8 * ((s) >> 1))
+#define NARROW_Q(q4) (4 * ((q4) & 1) + ((q4) >> 1))
+// column 4s + q4 of sample c = NARROW_S(s) + NARROW_Q(q4)
+__device__ __forceinline__ int narrow_col(int c) {
+    const int s = ((c >> 1) & 1) + 2 * ((c >> 3) & 1) + 4 * (c >> 4);
+    const int q4 = ((c >> 2) & 1) + 2 * (c & 1);
+    return 4 * s + q4;
+}
 
 // Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
 // wave, written to a buffer registered with ppo_debug_set_stamps().  Never compiled into the product.
@@ -222,19 +237,21 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
                     *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q) = v;
                 }
             if (h == 0) {
+                // narrow tiles: sample c = NARROW_S(s) + NARROW_Q(q4) is stored at column 4s + q4
+                const int col = L3_NARROW ? narrow_col(c) : c;
 #pragma unroll
-                for (int k = 0; k < AOUT; ++k) dtu[k * DT_LD + c] = dout[k];
+                for (int k = 0; k < AOUT; ++k) dtu[k * DT_LD + col] = dout[k];
             }
             if constexpr (L3_NARROW) {
                 const int c16 = lane & 15, q4 = lane >> 4;
                 const float* arow = dtu + min(c16, AOUT) * DT_LD + q4;          // row AOUT is zero; + 4 s
-                const float* bcol = h1s + q4 * W2_LD + c16;                       // + 4 s rows, + 16 t columns
+                const float* bcol = h1s + NARROW_Q(q4) * W2_LD + c16;             // + NARROW_S(s) rows, + 16 t columns
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const float av = arow[4 * s];
 #pragma unroll
                     for (int t4 = 0; t4 < 4; ++t4)
-                        gW3n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcol[4 * s * W2_LD + 16 * t4], gW3n[t4], 0, 0, 0);
+                        gW3n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcol[NARROW_S(s) * W2_LD + 16 * t4], gW3n[t4], 0, 0, 0);
                 }
             } else {
                 // k-step s of half-wave h is sample 16h + s
@@ -397,7 +414,6 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     const float* const hrow = h1s + c * W2_LD + 4 * h;
     const float* const zcol = dzs + (16 * h) * W2_LD + c;            // k-step s <-> sample 16h + s
     const float* const hcol = h1s + (16 * h) * W2_LD + c;
-    const float* const zcoln = dzs + q4 * W2_LD + c16;               // narrow: k-step s <-> sample 4s + q4
 
     // S <= 31: dZ1 has a buffer of its own, so the hand-off buffers are released BEFORE the layer-1
     // wgrad runs: its MFMAs overlap with the forward wave's (latency-bound) hand-off phase of the
@@ -405,13 +421,14 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     constexpr bool DEFER = L1 < 2;
     float* const z1row = ctx.dz1 + c * W2_LD + 4 * h;
     const float* const z1col = ctx.dz1 + (16 * h) * W2_LD + c;
-    const float* const z1coln = ctx.dz1 + q4 * W2_LD + c16;
+    const int nq = NARROW_Q(q4);                                      // narrow tiles: this lane group's first sample
+    const float* const z1coln = ctx.dz1 + nq * W2_LD + c16;
     float xp[NARROW ? 1 : 16][JT];
     float xq[NARROW ? 8 : 1];
     auto load_x = [&](int64_t m0) {
         // B operands of the layer-1 wgrad, X_aug[sample][input] (1 at input S, 0 beyond), fetched
         // ahead of the barriers so that they are long there when needed (lines the partner loaded a
-        // tile ago).  Wide: xp[s][jt] = X_aug[16h+s][32*jt+c].  Narrow: xq[s] = X_aug[4s+q4][c16].
+        // tile ago).  Wide: xp[s][jt] = X_aug[16h+s][32*jt+c].  Narrow: xq[s] = X_aug[NARROW_S(s)+nq][c16].
         const bool full = m0 + TILE_M <= a.n;
         // (S >= 32 only; the base goes through readfirstlane so that it provably lives in scalar registers)
         auto row_base = [&](int row) {
@@ -424,16 +441,16 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             const float fill = c16 == S ? 1.0f : 0.0f;
             const int inc = min(c16, S - 1);
             if (full) {
-                const float* p0 = a.states + (m0 + q4) * S + inc;
+                const float* p0 = a.states + (m0 + nq) * S + inc;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const float v = p0[(int64_t)(4 * s) * S];
+                    const float v = p0[(int64_t)NARROW_S(s) * S];
                     xq[s] = c16 < S ? v : fill;
                 }
             } else {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const int64_t gm = min(m0 + 4 * s + q4, a.n - 1);
+                    const int64_t gm = min(m0 + NARROW_S(s) + nq, a.n - 1);
                     const float v = a.states[gm * S + inc];
                     xq[s] = c16 < S ? v : fill;
                 }
@@ -480,7 +497,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
             for (int s = 0; s < 8; ++s) {
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4)
-                    gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(z1coln[4 * s * W2_LD + 16 * t4],
+                    gW1n[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(z1coln[NARROW_S(s) * W2_LD + 16 * t4],
                                                                      xq[s], gW1n[t4], 0, 0, 0);
             }
         } else {
