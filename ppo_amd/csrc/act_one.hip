@@ -18,17 +18,25 @@
 //  * ppo_act_session_*: the launch itself leaves the critical path.  A kernel is launched BEFORE
 //    its state exists: it loads its weights, then polls a mailbox in page-locked host memory for
 //    the request (bounded: it gives up after about a millisecond, or when told to), serves it, and
-//    exits.  Request numbers are 1 .. 2^31 - 1; the top bit of the mailbox word withdraws the
+//    exits.  Request numbers are 1 .. 2^31 - 1; a control word of the mailbox withdraws the
 //    waiter.  Each step posts its request and launches the kernel for the step after, so that launch
 //    overlaps the device's work on this step.  Every kernel serves at most one request and always
 //    terminates on its own; kernels of one session run on the session's own stream, one after the
 //    other, which is what lets them pass "last request served" through a device word.
+//    A read of host memory is a PCIe round trip of more than a microsecond, and a store that has to
+//    be acknowledged before the next one may go costs as much again, so the protocol is built to need
+//    ONE read round trip and NO acknowledged store per step: request and reply travel as 16-bit
+//    halves, each in a dword of its own whose upper half is the low 16 bits of the request number.
+//    A dword is read and written whole, so every dword says by itself which request it belongs to:
+//    the poll IS the fetch of the request (a poll that finds every dword on the same new number has
+//    the whole request, whatever order the host's stores and the device's loads were performed in),
+//    and the host accepts a reply once every dword of it carries the number it posted.  What stays
+//    the same from step to step (buffer columns, seed, variance) travels in the launch's arguments.
 #include "ppo_common.h"
 #include <stddef.h>
 #include <string.h>
 
-struct ActRequest {   // one 64-byte line; seq is written last (host) and read first (device).  The
-    // kernel reads the line as 16 dwords and reassembles the fields: keep this order and these sizes.
+struct ActRequest {   // one step's rows and random stream (immediate form: in the launch's arguments)
     float* state_row;
     void* action_row;
     float* logprob_row;
@@ -39,16 +47,29 @@ struct ActRequest {   // one 64-byte line; seq is written last (host) and read f
     unsigned pad[2];
 };
 
-static_assert(sizeof(ActRequest) == 64 && offsetof(ActRequest, seed) == 32 && offsetof(ActRequest, action_var) == 48 &&
-              offsetof(ActRequest, seq) == 52, "the kernel reads ActRequest by dword index");
+// Tagged halves: dword = (request number & 0xffff) << 16 | 16 bits of payload.
+// Request payload, in halves: [0..1] row (32 bits), [2..5] rng_offset (64 bits), [6 + 2u, 7 + 2u] input u.
+#define ACT_REQ_HALVES(S) (6 + 2 * (S))
+#define ACT_REQ_MAX 192                // >= ACT_REQ_HALVES(PPO_MAX_STATE_DIM), three dwords per lane at most
+static_assert(ACT_REQ_HALVES(PPO_MAX_STATE_DIM) <= ACT_REQ_MAX, "request does not fit three dwords per lane");
 
 struct ActMailbox {   // page-locked host memory
-    ActRequest req;                 // host -> device
-    float state[64];                // host -> device
-    float action[8];                // device -> host (int32 in word 0 for a discrete policy)
-    unsigned ticket;                //   seq of the last request served
-    unsigned unserved;              //   kernels that gave up waiting so far (only grows)
-    unsigned pad[6];
+    unsigned req[ACT_REQ_MAX];      // host -> device: the request as tagged halves
+    unsigned ctrl;                  // host -> device: ACT_CANCEL_BIT withdraws the waiter
+    unsigned pad0[15];
+    uint64_t reply[8];              // device -> host: the action words as tagged halves (int32 in word 0 for
+                                    //   a discrete policy), two dwords per word (one 8-byte store each)
+    unsigned unserved;              // device -> host: kernels that gave up waiting so far (only grows)
+    unsigned pad1[15];
+};
+
+struct ActBound {   // what the waiting kernel is launched with: the buffer's columns (dense rows) and the stream of draws
+    float* states;
+    char* actions;
+    float* logprobs;
+    float* values;
+    uint64_t seed;
+    float action_var;
 };
 
 struct OneState {   // the observation, passed by value: it reaches the device with the launch itself
@@ -64,19 +85,22 @@ __device__ __forceinline__ T host_load(const T* p) {   // a load that always goe
 }
 
 // mb == nullptr: serve (req, state) from the arguments now, report through host_action_out / host_ticket.
-// mb != nullptr: wait until the mailbox holds a request number other than words[0] (words: device
-// memory, [0] = last request served, [1] = kernels that gave up), serve it, report through the mailbox.
+// mb != nullptr: wait until the mailbox holds a request with a number other than words[0] (words: device
+// memory, [0] = last request served, [1] = kernels that gave up), serve it on row `row` of the bound
+// columns, report through the mailbox.
 template <bool CONT, int AMAX, bool WAIT>
 __device__ __forceinline__ void act_one_body(const float* __restrict__ params, int S, int A,
                                              ActRequest req, const OneState* state,
                                              void* host_action_out, unsigned* host_ticket,
-                                             ActMailbox* mb_arg, unsigned* words, unsigned wait_ticks) {
+                                             ActMailbox* mb_arg, unsigned* words, unsigned wait_ticks,
+                                             const ActBound* bound) {
     // every multiply and add below is rounded as written (a prescale product must be rounded before
     // it enters the chain, as the tile kernels' staged images are)
 #pragma clang fp contract(off)
     ActMailbox* const mb = WAIT ? mb_arg : nullptr;
     __shared__ float h2s[2][HID];
-    __shared__ int go;
+    __shared__ float xs[HID];
+    __shared__ unsigned go, go_row;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), u = threadIdx.x & 63;
     const int aout = wave ? 1 : A;
     const NetLayout PA = net_layout(0, S, A);
@@ -103,21 +127,46 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
     unsigned expect = 0;
     float xv = 0.f;
     if constexpr (WAIT) {
-        if (threadIdx.x == 0) {
+        if (wave == 0) {
+            // The whole wave polls: lane i fetches dwords i, i + 64 and i + 128 of the request, lane 0 the
+            // control word too, all in flight together: one round trip to the host's memory per poll.
             const unsigned served = words[0];
-            unsigned g = 0;
+            const int nd = ACT_REQ_HALVES(S);
+            const bool has0 = u < nd, has1 = u + 64 < nd, has2 = u + 128 < nd;
+            unsigned g = 0, w0 = 0, w1 = 0, w2 = 0;
             const uint64_t t0 = wall_clock64();
-            for (unsigned it = 0; it < ACT_MAX_POLLS; ++it) {   // a poll is one read of host memory: about a microsecond
-                const unsigned s = host_load(&mb->req.seq);
-                if (s & ACT_CANCEL_BIT) break;
-                if (s != served) { g = s; break; }
+            for (unsigned it = 0; it < ACT_MAX_POLLS; ++it) {
+                if (has0) w0 = host_load(&mb->req[u]);
+                if (has1) w1 = host_load(&mb->req[u + 64]);
+                if (has2) w2 = host_load(&mb->req[u + 128]);
+                const unsigned ctl = u == 0 ? host_load(&mb->ctrl) : 0u;
+                if (__builtin_amdgcn_readfirstlane(ctl) & ACT_CANCEL_BIT) break;
+                const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(w0) >> 16;
+                const bool torn = (has0 && (w0 >> 16) != t) || (has1 && (w1 >> 16) != t) || (has2 && (w2 >> 16) != t);
+                const unsigned ahead = (t - served) & 0xffffu;   // requests are numbered consecutively
+                if (ahead != 0 && !__any(torn)) { g = served + ahead; break; }
                 if ((it & 7) == 7 && wall_clock64() - t0 > wait_ticks) break;
             }
-            go = (int)g;
+            if (g) {
+                // lane u's input: halves 6 + 2u and 7 + 2u
+                const int i0 = 6 + 2 * u, i1 = i0 + 1;
+                unsigned lo = __shfl(w0, i0 & 63), hi = __shfl(w0, i1 & 63);
+                if (nd > 64) {   // (wave-uniform)
+                    const unsigned lo1 = __shfl(w1, i0 & 63), hi1 = __shfl(w1, i1 & 63);
+                    const unsigned lo2 = __shfl(w2, i0 & 63), hi2 = __shfl(w2, i1 & 63);
+                    lo = (i0 >> 6) == 0 ? lo : ((i0 >> 6) == 1 ? lo1 : lo2);
+                    hi = (i1 >> 6) == 0 ? hi : ((i1 >> 6) == 1 ? hi1 : hi2);
+                }
+                if (u < S) xs[u] = __uint_as_float((lo & 0xffffu) | (hi << 16));
+                auto half = [&](int i) { return (uint64_t)((unsigned)__builtin_amdgcn_readlane(w0, i) & 0xffffu); };
+                req.rng_offset = half(2) | half(3) << 16 | half(4) << 32 | half(5) << 48;
+                if (u == 0) go_row = (unsigned)(half(0) | half(1) << 16);
+            }
+            if (u == 0) go = g;
         }
         __syncthreads();
-        expect = (unsigned)go;
-        if (!go) {   // nobody came: say so and leave
+        expect = go;
+        if (!expect) {   // nobody came: say so and leave
             if (threadIdx.x == 0) {
                 const unsigned n = words[1] + 1;
                 words[1] = n;
@@ -125,18 +174,14 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
             }
             return;
         }
-        // the request in ONE round trip: lane i takes dword (i & 15) of the request line, lane u < S
-        // its input (loads that go to the host's memory every time; nothing cached to invalidate)
-        const int rw = (int)host_load(reinterpret_cast<const unsigned*>(&mb->req) + (u & 15));
-        if (u < S) xv = host_load(&mb->state[u]);
-        auto word = [&](int i) { return (uint64_t)(unsigned)__builtin_amdgcn_readlane(rw, i); };
-        req.state_row = reinterpret_cast<float*>(word(0) | word(1) << 32);
-        req.action_row = reinterpret_cast<void*>(word(2) | word(3) << 32);
-        req.logprob_row = reinterpret_cast<float*>(word(4) | word(5) << 32);
-        req.value_row = reinterpret_cast<float*>(word(6) | word(7) << 32);
-        req.seed = word(8) | word(9) << 32;
-        req.rng_offset = word(10) | word(11) << 32;
-        req.action_var = __uint_as_float((unsigned)word(12));
+        if (u < S) xv = xs[u];
+        const size_t row = go_row;
+        req.state_row = bound->states + row * S;
+        req.action_row = bound->actions + row * (sizeof(float) * (CONT ? (size_t)A : 1));
+        req.logprob_row = bound->logprobs + row;
+        req.value_row = bound->values + row;
+        req.seed = bound->seed;
+        req.action_var = bound->action_var;
     } else {
         if (u < S) xv = state->v[u];
     }
@@ -193,44 +238,63 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
                                           req.action_row, logp, ent, action, act_c);
         if (u == 0) req.logprob_row[0] = logp;
     }
-    __syncthreads();   // the critic's row is written too: the ticket below vouches for the whole step
+    __syncthreads();   // the critic's row is written too: the reply below vouches for the whole step
     if (threadIdx.x == 0) {
-        void* const out = mb ? (void*)mb->action : host_action_out;
-        if constexpr (CONT) {
-#pragma unroll
-            for (int k = 0; k < AMAX; ++k) if (k < A) reinterpret_cast<float*>(out)[k] = act_c[k];
-        } else {
-            reinterpret_cast<int*>(out)[0] = action;
-        }
-        unsigned* const tick = mb ? &mb->ticket : host_ticket;
-        if (mb) words[0] = expect;
-        if (tick) {
+        if constexpr (WAIT) {
+            words[0] = expect;
+            // the four rows (device memory: acknowledged within the device) become visible to every
+            // stream before the reply leaves; the reply's own stores wait for nothing
             __threadfence_system();
-            __hip_atomic_store(tick, mb ? expect : req.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned tag = expect << 16;
+            auto put = [&](int k, unsigned word) {
+                const uint64_t v = (uint64_t)(tag | (word & 0xffffu)) | (uint64_t)(tag | (word >> 16)) << 32;
+                __hip_atomic_store(&mb->reply[k], v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            };
+            if constexpr (CONT) {
+#pragma unroll
+                for (int k = 0; k < AMAX; ++k) if (k < A) put(k, __float_as_uint(act_c[k]));
+            } else {
+                put(0, (unsigned)action);
+            }
+        } else {
+            if constexpr (CONT) {
+#pragma unroll
+                for (int k = 0; k < AMAX; ++k) if (k < A) reinterpret_cast<float*>(host_action_out)[k] = act_c[k];
+            } else {
+                reinterpret_cast<int*>(host_action_out)[0] = action;
+            }
+            if (host_ticket) {
+                __threadfence_system();
+                __hip_atomic_store(host_ticket, req.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
 
 // Two entry points of the same body: the immediate form carries request and state in its arguments
-// (320 bytes); the waiting form's launch is on the caller's critical path, so it carries 40.
+// (320 bytes); the waiting form's launch is on the caller's critical path, so it carries 88.
 template <bool CONT, int AMAX>
 __global__ __launch_bounds__(128) void act_one_kernel(const float* __restrict__ params, int S, int A,
                                                       const ActRequest req, const OneState state,
                                                       void* host_action_out, unsigned* host_ticket) {
-    act_one_body<CONT, AMAX, false>(params, S, A, req, &state, host_action_out, host_ticket, nullptr, nullptr, 0);
+    act_one_body<CONT, AMAX, false>(params, S, A, req, &state, host_action_out, host_ticket, nullptr, nullptr, 0,
+                                    nullptr);
 }
 
 template <bool CONT, int AMAX>
 __global__ __launch_bounds__(128) void act_wait_kernel(const float* __restrict__ params, int S, int A,
-                                                       ActMailbox* mb, unsigned* words, unsigned wait_ticks) {
-    act_one_body<CONT, AMAX, true>(params, S, A, ActRequest{}, nullptr, nullptr, nullptr, mb, words, wait_ticks);
+                                                       ActMailbox* mb, unsigned* words, unsigned wait_ticks,
+                                                       const ActBound bound) {
+    act_one_body<CONT, AMAX, true>(params, S, A, ActRequest{}, nullptr, nullptr, nullptr, mb, words, wait_ticks,
+                                   &bound);
 }
 
 static int launch_one(const float* params, int S, int A, int continuous, const ActRequest& req,
                       const OneState& state, void* host_action_out, unsigned* host_ticket, ActMailbox* mb,
-                      unsigned* words, unsigned wait_ticks, hipStream_t st) {
+                      unsigned* words, unsigned wait_ticks, const ActBound& bound, hipStream_t st) {
 #define ACT_ONE(C, AM)                                                                              \
-    if (mb) act_wait_kernel<C, AM><<<1, 128, 0, st>>>(params, S, A, mb, words, wait_ticks);              \
+    if (mb) act_wait_kernel<C, AM><<<1, 128, 0, st>>>(params, S, A, mb, words, wait_ticks, bound);       \
     else act_one_kernel<C, AM><<<1, 128, 0, st>>>(params, S, A, req, state, host_action_out, host_ticket)
     if (continuous) {
         if (A <= 4) { ACT_ONE(true, 4); } else { ACT_ONE(true, 8); }
@@ -272,7 +336,7 @@ extern "C" int ppo_act_host(const float* params, int state_dim, int action_dim, 
     req.value_row = value_row; req.seed = seed; req.rng_offset = rng_offset; req.action_var = action_var;
     req.seq = ticket;
     const int rc = launch_one(params, state_dim, action_dim, continuous, req, state, host_action_out,
-                              host_ticket, nullptr, nullptr, 0, st);
+                              host_ticket, nullptr, nullptr, 0, ActBound{}, st);
     if (rc) return rc;
     if (!host_ticket) return (int)hipStreamSynchronize(st);
     return spin_for(host_ticket, ticket, st);
@@ -285,33 +349,33 @@ struct ppo_act_session {
     hipStream_t stream;       // the session's own stream (non-blocking)
     hipEvent_t after;         // orders the first kernel after a drain behind the caller's stream
     int S, A, continuous;
-    const float* params;      // weights the waiting kernels were launched with
-    uint64_t version;         // ... and the caller's version number of their contents
     unsigned seq;             // last request posted
     unsigned seen_unserved;
     int inflight;             // kernels launched and not yet known to have ended
     unsigned wait_ticks;
     // ppo_act_session_bind: everything of a step that does not change from step to step
-    struct {
+    struct Binding {
         const float* params;
-        uint64_t version, seed;
-        float action_var;
+        uint64_t version;
+        ActBound dev;         // what the waiting kernels carry in their arguments
         const float* host_state;
         void* action_out;
-        float* states;
-        char* actions;
-        float* logprobs;
-        float* values;
         void* after_stream;
         bool set;
-    } bound;
+    } bound, launched;        // launched: what the kernels now in flight were launched under
 };
+
+static bool same_launch(const ppo_act_session::Binding& a, const ppo_act_session::Binding& b) {
+    return a.params == b.params && a.version == b.version && a.dev.states == b.dev.states &&
+           a.dev.actions == b.dev.actions && a.dev.logprobs == b.dev.logprobs && a.dev.values == b.dev.values &&
+           a.dev.seed == b.dev.seed && memcmp(&a.dev.action_var, &b.dev.action_var, sizeof(float)) == 0;
+}
 
 static int session_launch(ppo_act_session* s) {
     const ActRequest none{};
     const OneState no_state{};
-    const int rc = launch_one(s->params, s->S, s->A, s->continuous, none, no_state, nullptr, nullptr, s->mb,
-                              s->words, s->wait_ticks, s->stream);
+    const int rc = launch_one(s->launched.params, s->S, s->A, s->continuous, none, no_state, nullptr, nullptr, s->mb,
+                              s->words, s->wait_ticks, s->launched.dev, s->stream);
     if (!rc) ++s->inflight;
     return rc;
 }
@@ -325,7 +389,7 @@ extern "C" int ppo_act_session_create(ppo_act_session** out, int state_dim, int 
     s->S = state_dim; s->A = action_dim; s->continuous = continuous;
     s->wait_ticks = (unsigned)wait_us * 100u;   // wall_clock64 counts at 100 MHz
     // The protocol needs fine-grained coherent host memory (the device's system-scope loads must see the
-    // host's stores and the host the ticket): asked for explicitly, whatever HIP_HOST_COHERENT says.
+    // host's stores and the host the reply): asked for explicitly, whatever HIP_HOST_COHERENT says.
     hipError_t e = hipHostMalloc((void**)&s->mb, sizeof(ActMailbox), hipHostMallocCoherent);
     if (e == hipSuccess) e = hipMalloc((void**)&s->words, 2 * sizeof(unsigned));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -350,8 +414,9 @@ extern "C" int ppo_act_session_create(ppo_act_session** out, int state_dim, int 
 // this the rows written so far are visible to any stream, and the weights may change.
 extern "C" int ppo_act_session_drain(ppo_act_session* s) {
     if (!s) return PPO_E_BADARG;
-    if (s->inflight) __atomic_store_n(&s->mb->req.seq, s->seq | ACT_CANCEL_BIT, __ATOMIC_RELEASE);
+    if (s->inflight) __atomic_store_n(&s->mb->ctrl, ACT_CANCEL_BIT, __ATOMIC_RELEASE);
     const hipError_t e = hipStreamSynchronize(s->stream);
+    __atomic_store_n(&s->mb->ctrl, 0u, __ATOMIC_RELEASE);
     s->inflight = 0;
     s->seen_unserved = __atomic_load_n(&s->mb->unserved, __ATOMIC_ACQUIRE);
     return (int)e;
@@ -368,23 +433,45 @@ extern "C" int ppo_act_session_destroy(ppo_act_session* s) {
     return rc;
 }
 
-extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, uint64_t params_version,
-                                    float action_var,
-                                    const float* host_state, uint64_t seed, uint64_t rng_offset,
-                                    float* state_row, void* action_row, float* logprob_row,
-                                    float* value_row, void* action_out, void* after_stream) {
-    if (!s || !params || !host_state || !state_row || !action_row || !logprob_row || !value_row || !action_out)
+// What stays the same from step to step is bound once: the weights and their version, the variance,
+// the host's state / action buffers, the seed and the four buffer columns (dense rows: state_dim
+// floats, one int32 or action_dim floats, one float, one float).  The columns, the seed and the
+// variance travel in the waiting kernel's launch arguments, the weights are loaded at its launch, one
+// step early: a step under another binding than the waiting kernel's withdraws that kernel first.
+extern "C" int ppo_act_session_bind(ppo_act_session* s, const float* params, uint64_t params_version,
+                                    float action_var, const float* host_state, void* action_out,
+                                    uint64_t seed, float* states, void* actions, float* logprobs,
+                                    float* values, void* after_stream) {
+    if (!s || !params || !host_state || !action_out || !states || !actions || !logprobs || !values)
         return PPO_E_BADARG;
-    // The kernel that waits for this request was launched a step ago and loaded its weight rows then.
-    // Other weights - another vector, or the same vector written since (the caller's version number
-    // moved) - or a used-up counter: withdraw it and start over with a kernel launched now.
-    if (s->params != params || s->version != params_version || s->seq >= 0x7ffffff0u) {
+    s->bound.params = params;
+    s->bound.version = params_version;
+    s->bound.dev.states = states;
+    s->bound.dev.actions = (char*)actions;
+    s->bound.dev.logprobs = logprobs;
+    s->bound.dev.values = values;
+    s->bound.dev.seed = seed;
+    s->bound.dev.action_var = action_var;
+    s->bound.host_state = host_state;
+    s->bound.action_out = action_out;
+    s->bound.after_stream = after_stream;
+    s->bound.set = true;
+    return 0;
+}
+
+extern "C" int ppo_act_session_step_bound(ppo_act_session* s, int64_t row, uint64_t rng_offset) {
+    if (!s || !s->bound.set || row < 0 || row > 0xffffffffll) return PPO_E_BADARG;
+    // The kernel that waits for this request was launched a step ago, under the binding of that moment.
+    // Another binding - other weights, or the same vector written since (the caller's version number
+    // moved), other columns, seed or variance - or a used-up counter: withdraw it and start over with a
+    // kernel launched now.
+    if (!same_launch(s->bound, s->launched) || s->seq >= 0x7ffffff0u) {
         const int rc = ppo_act_session_drain(s);
         if (rc) return rc;
-        s->params = params;
-        s->version = params_version;
+        s->launched = s->bound;
         if (s->seq >= 0x7ffffff0u) {
             s->seq = 0;
+            memset(s->mb->req, 0, sizeof(s->mb->req));                                  // no dword may carry an old number
             hipError_t e = hipMemsetAsync(s->words, 0, sizeof(unsigned), s->stream);   // the drained stream is idle
             if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
             if (e != hipSuccess) return (int)e;
@@ -392,23 +479,41 @@ extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, uin
     }
     ActMailbox* const mb = s->mb;
     const unsigned k = ++s->seq;
-    memcpy(mb->state, host_state, sizeof(float) * s->S);
-    mb->req.state_row = state_row; mb->req.action_row = action_row; mb->req.logprob_row = logprob_row;
-    mb->req.value_row = value_row; mb->req.seed = seed; mb->req.rng_offset = rng_offset;
-    mb->req.action_var = action_var;
-    __atomic_store_n(&mb->req.seq, k, __ATOMIC_RELEASE);
+    const unsigned tag = k << 16;
+    {   // the request as tagged halves; no store has to be ordered against another
+        unsigned* const q = mb->req;
+        auto put = [&](int i, unsigned half) { __atomic_store_n(&q[i], tag | (half & 0xffffu), __ATOMIC_RELAXED); };
+        put(0, (unsigned)row); put(1, (unsigned)row >> 16);
+        put(2, (unsigned)rng_offset); put(3, (unsigned)(rng_offset >> 16));
+        put(4, (unsigned)(rng_offset >> 32)); put(5, (unsigned)(rng_offset >> 48));
+        const float* const x = s->bound.host_state;
+        for (int u = 0; u < s->S; ++u) {
+            unsigned w;
+            memcpy(&w, &x[u], 4);
+            put(6 + 2 * u, w); put(7 + 2 * u, w >> 16);
+        }
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+    }
     int rc = 0;
     if (s->inflight == 0) {                           // nobody is waiting for this request
         // first kernel since the drain: it must see what the caller's stream did meanwhile (new weights)
-        hipError_t e = hipEventRecord(s->after, (hipStream_t)after_stream);
+        hipError_t e = hipEventRecord(s->after, (hipStream_t)s->bound.after_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->after, 0);
         if (e != hipSuccess) return (int)e;
         rc = session_launch(s);
     }
     if (!rc) rc = session_launch(s);                  // the kernel for the NEXT request: overlaps this one
     if (rc) return rc;
+    const int nw = s->continuous ? s->A : 1;          // action words; two tagged dwords each
+    unsigned r[16];
+    const unsigned* const reply = reinterpret_cast<const unsigned*>(mb->reply);
     for (unsigned spins = 1;; ++spins) {
-        if (__atomic_load_n(&mb->ticket, __ATOMIC_ACQUIRE) == k) break;
+        bool all = true;
+        for (int i = 0; i < 2 * nw; ++i) {
+            r[i] = __atomic_load_n(&reply[i], __ATOMIC_RELAXED);
+            all = all && (r[i] & 0xffff0000u) == tag;
+        }
+        if (all) break;
         const unsigned gave_up = __atomic_load_n(&mb->unserved, __ATOMIC_ACQUIRE);
         if (gave_up != s->seen_unserved) {            // waiting kernels that left before the request came
             s->inflight -= (int)(gave_up - s->seen_unserved);
@@ -421,48 +526,45 @@ extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, uin
         if ((spins & 0xffff) == 0) {
             const hipError_t q = hipStreamQuery(s->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
-            if (q == hipSuccess && __atomic_load_n(&mb->ticket, __ATOMIC_ACQUIRE) != k &&
+            if (q == hipSuccess && (__atomic_load_n(&reply[0], __ATOMIC_RELAXED) & 0xffff0000u) != tag &&
                 __atomic_load_n(&mb->unserved, __ATOMIC_ACQUIRE) == s->seen_unserved)
                 return (int)hipErrorUnknown;          // every kernel ended, none served, none gave up
         }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     --s->inflight;                                     // the kernel that served k
-    memcpy(action_out, mb->action, sizeof(float) * (s->continuous ? s->A : 1));
+    unsigned* const out = (unsigned*)s->bound.action_out;
+    for (int i = 0; i < nw; ++i) out[i] = (r[2 * i] & 0xffffu) | (r[2 * i + 1] << 16);
     return 0;
 }
 
-// The per-step call of a host loop costs mostly argument marshalling in the binding (twelve arguments
-// of ppo_act_session_step against three here), so the arguments that stay the same from step to step
-// are bound once: the weights and their version, the variance, the page-locked state / action
-// buffers, the seed and the four buffer columns (dense rows: state_dim floats, one int32 or
-// action_dim floats, one float, one float).  Bind again whenever one of them changes (new weights
-// or version, another variance, moved columns, another stream to order the first kernel behind).
-extern "C" int ppo_act_session_bind(ppo_act_session* s, const float* params, uint64_t params_version,
-                                    float action_var, const float* host_state, void* action_out,
-                                    uint64_t seed, float* states, void* actions, float* logprobs,
-                                    float* values, void* after_stream) {
-    if (!s || !params || !host_state || !action_out || !states || !actions || !logprobs || !values)
+// One step with everything given per call.  Served through the binding: a call whose rows are row r of
+// the columns bound so far (same weights, version, variance, seed, host buffers and stream) is that
+// binding's step r - a caller that walks down its buffer row by row keeps its waiting kernel - and any
+// other call binds anew, with its rows as row 0.
+extern "C" int ppo_act_session_step(ppo_act_session* s, const float* params, uint64_t params_version,
+                                    float action_var,
+                                    const float* host_state, uint64_t seed, uint64_t rng_offset,
+                                    float* state_row, void* action_row, float* logprob_row,
+                                    float* value_row, void* action_out, void* after_stream) {
+    if (!s || !params || !host_state || !state_row || !action_row || !logprob_row || !value_row || !action_out)
         return PPO_E_BADARG;
-    s->bound.params = params;
-    s->bound.version = params_version;
-    s->bound.seed = seed;
-    s->bound.action_var = action_var;
-    s->bound.host_state = host_state;
-    s->bound.action_out = action_out;
-    s->bound.states = states;
-    s->bound.actions = (char*)actions;
-    s->bound.logprobs = logprobs;
-    s->bound.values = values;
-    s->bound.after_stream = after_stream;
-    s->bound.set = true;
-    return 0;
-}
-
-extern "C" int ppo_act_session_step_bound(ppo_act_session* s, int64_t row, uint64_t rng_offset) {
-    if (!s || !s->bound.set || row < 0) return PPO_E_BADARG;
-    const size_t action_bytes = sizeof(float) * (s->continuous ? (size_t)s->A : 1);   // int32 and float are 4 bytes
-    return ppo_act_session_step(s, s->bound.params, s->bound.version, s->bound.action_var, s->bound.host_state,
-                                s->bound.seed, rng_offset, s->bound.states + row * s->S,
-                                s->bound.actions + row * action_bytes, s->bound.logprobs + row,
-                                s->bound.values + row, s->bound.action_out, s->bound.after_stream);
+    const ptrdiff_t action_bytes = (ptrdiff_t)sizeof(float) * (s->continuous ? s->A : 1);
+    int64_t row = -1;
+    const ppo_act_session::Binding& b = s->bound;
+    if (b.set && b.params == params && b.version == params_version && b.dev.seed == seed &&
+        memcmp(&b.dev.action_var, &action_var, sizeof(float)) == 0 && b.host_state == host_state &&
+        b.action_out == action_out && b.after_stream == after_stream) {
+        const ptrdiff_t r = logprob_row - b.dev.logprobs;
+        if (r >= 0 && r <= 0xffffffffll && value_row == b.dev.values + r && state_row == b.dev.states + r * s->S &&
+            (char*)action_row == b.dev.actions + r * action_bytes)
+            row = r;
+    }
+    if (row < 0) {
+        const int rc = ppo_act_session_bind(s, params, params_version, action_var, host_state, action_out, seed,
+                                            state_row, action_row, logprob_row, value_row, after_stream);
+        if (rc) return rc;
+        row = 0;
+    }
+    return ppo_act_session_step_bound(s, row, rng_offset);
 }
