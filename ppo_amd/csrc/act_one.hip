@@ -17,12 +17,11 @@
 //    page-locked memory instead of waiting for the stream.
 //  * ppo_act_session_*: the launch itself leaves the critical path.  A kernel is launched BEFORE
 //    its state exists: it loads its weights, then polls a mailbox in page-locked host memory for
-//    the request (bounded: it gives up after about a millisecond, or when told to), serves it, and
-//    exits.  Request numbers are 1 .. 2^31 - 1; a control word of the mailbox withdraws the
-//    waiter.  Each step posts its request and launches the kernel for the step after, so that launch
-//    overlaps the device's work on this step.  Every kernel serves at most one request and always
-//    terminates on its own; kernels of one session run on the session's own stream, one after the
-//    other, which is what lets them pass "last request served" through a device word.
+//    the request, serves it and goes back to polling, its weight rows still in registers.  It always
+//    terminates on its own: when no request has come for about a millisecond (configurable), or when a
+//    control word of the mailbox withdraws it; a step that finds no kernel waiting launches one.
+//    Request numbers are 1 .. 2^31 - 1.  Kernels of one session run on the session's own stream, one
+//    after the other, which is what lets them pass "last request served" through a device word.
 //    A read of host memory is a PCIe round trip of more than a microsecond, and a store that has to
 //    be acknowledged before the next one may go costs as much again, so the protocol is built to need
 //    ONE read round trip and NO acknowledged store per step: request and reply travel as 16-bit
@@ -114,6 +113,14 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
     float w1a[8];   // the first eight inputs' weights (all of them for most envs)
 #pragma unroll
     for (int j = 0; j < 8; ++j) w1a[j] = j < S ? params[P.w1 + u * S + j] : 0.f;
+    float w1b[24];  // inputs 8 .. 31 (the widest observations of the reference's envs are 24 - 28 values)
+    if (S > 8) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) w1b[j] = 8 + j < S ? params[P.w1 + u * S + 8 + j] : 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) w1b[j] = 0.f;
+    }
     // out layer: lane 4 a + g sums class g of output a (16 units, ascending)
     const int oa = u >> 2, og = u & 3;
     const bool out_lane = oa < aout;
@@ -124,13 +131,15 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) b3[a] = a < aout ? params[P.b3 + a] : 0.f;
 
+    unsigned served = 0;   // (waiting form) the last request served, by this kernel or the one before it
+    if constexpr (WAIT) served = words[0];
+    for (;;) {
     unsigned expect = 0;
     float xv = 0.f;
     if constexpr (WAIT) {
         if (wave == 0) {
             // The whole wave polls: lane i fetches dwords i, i + 64 and i + 128 of the request, lane 0 the
             // control word too, all in flight together: one round trip to the host's memory per poll.
-            const unsigned served = words[0];
             const int nd = ACT_REQ_HALVES(S);
             const bool has0 = u < nd, has1 = u + 64 < nd, has2 = u + 128 < nd;
             unsigned g = 0, w0 = 0, w1 = 0, w2 = 0;
@@ -166,7 +175,7 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
         }
         __syncthreads();
         expect = go;
-        if (!expect) {   // nobody came: say so and leave
+        if (!expect) {   // nobody came within the waiting time, or the waiter was withdrawn: say so and leave
             if (threadIdx.x == 0) {
                 const unsigned n = words[1] + 1;
                 words[1] = n;
@@ -192,7 +201,12 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
 #pragma unroll
     for (int j = 0; j < 8; ++j)   // a zero weight (input >= S) leaves z as it is
         z = fmaf(w1a[j] * TANH_PRESCALE, __int_as_float(__builtin_amdgcn_readlane(xb, j)), z);
-    for (int k0 = 8; k0 < S; k0 += 8) {   // eight loads in flight
+    if (S > 8) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j)
+            z = fmaf(w1b[j] * TANH_PRESCALE, __int_as_float(__builtin_amdgcn_readlane(xb, 8 + j)), z);
+    }
+    for (int k0 = 32; k0 < S; k0 += 8) {   // eight loads in flight
         float w[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = k0 + j < S ? params[P.w1 + u * S + k0 + j] : 0.f;
@@ -269,6 +283,11 @@ __device__ __forceinline__ void act_one_body(const float* __restrict__ params, i
                 __hip_atomic_store(host_ticket, req.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+    }
+    if constexpr (!WAIT) break;
+    // the waiting form goes back to its mailbox (the barrier above separates this request's reads of
+    // xs / go / h2s from the next one's writes)
+    served = expect;
     }
 }
 
@@ -351,7 +370,7 @@ struct ppo_act_session {
     int S, A, continuous;
     unsigned seq;             // last request posted
     unsigned seen_unserved;
-    int inflight;             // kernels launched and not yet known to have ended
+    int live;                 // a kernel has been launched and is not yet known to have ended
     unsigned wait_ticks;
     // ppo_act_session_bind: everything of a step that does not change from step to step
     struct Binding {
@@ -376,7 +395,7 @@ static int session_launch(ppo_act_session* s) {
     const OneState no_state{};
     const int rc = launch_one(s->launched.params, s->S, s->A, s->continuous, none, no_state, nullptr, nullptr, s->mb,
                               s->words, s->wait_ticks, s->launched.dev, s->stream);
-    if (!rc) ++s->inflight;
+    if (!rc) s->live = 1;
     return rc;
 }
 
@@ -414,10 +433,10 @@ extern "C" int ppo_act_session_create(ppo_act_session** out, int state_dim, int 
 // this the rows written so far are visible to any stream, and the weights may change.
 extern "C" int ppo_act_session_drain(ppo_act_session* s) {
     if (!s) return PPO_E_BADARG;
-    if (s->inflight) __atomic_store_n(&s->mb->ctrl, ACT_CANCEL_BIT, __ATOMIC_RELEASE);
+    if (s->live) __atomic_store_n(&s->mb->ctrl, ACT_CANCEL_BIT, __ATOMIC_RELEASE);
     const hipError_t e = hipStreamSynchronize(s->stream);
     __atomic_store_n(&s->mb->ctrl, 0u, __ATOMIC_RELEASE);
-    s->inflight = 0;
+    s->live = 0;
     s->seen_unserved = __atomic_load_n(&s->mb->unserved, __ATOMIC_ACQUIRE);
     return (int)e;
 }
@@ -436,8 +455,8 @@ extern "C" int ppo_act_session_destroy(ppo_act_session* s) {
 // What stays the same from step to step is bound once: the weights and their version, the variance,
 // the host's state / action buffers, the seed and the four buffer columns (dense rows: state_dim
 // floats, one int32 or action_dim floats, one float, one float).  The columns, the seed and the
-// variance travel in the waiting kernel's launch arguments, the weights are loaded at its launch, one
-// step early: a step under another binding than the waiting kernel's withdraws that kernel first.
+// variance travel in the waiting kernel's launch arguments, the weights are loaded at its launch:
+// a step under another binding than the waiting kernel's withdraws that kernel first.
 extern "C" int ppo_act_session_bind(ppo_act_session* s, const float* params, uint64_t params_version,
                                     float action_var, const float* host_state, void* action_out,
                                     uint64_t seed, float* states, void* actions, float* logprobs,
@@ -461,7 +480,7 @@ extern "C" int ppo_act_session_bind(ppo_act_session* s, const float* params, uin
 
 extern "C" int ppo_act_session_step_bound(ppo_act_session* s, int64_t row, uint64_t rng_offset) {
     if (!s || !s->bound.set || row < 0 || row > 0xffffffffll) return PPO_E_BADARG;
-    // The kernel that waits for this request was launched a step ago, under the binding of that moment.
+    // The kernel that waits for this request was launched earlier, under the binding of that moment.
     // Another binding - other weights, or the same vector written since (the caller's version number
     // moved), other columns, seed or variance - or a used-up counter: withdraw it and start over with a
     // kernel launched now.
@@ -495,15 +514,13 @@ extern "C" int ppo_act_session_step_bound(ppo_act_session* s, int64_t row, uint6
         __atomic_thread_fence(__ATOMIC_RELEASE);
     }
     int rc = 0;
-    if (s->inflight == 0) {                           // nobody is waiting for this request
+    if (!s->live) {                                   // nobody is waiting for this request
         // first kernel since the drain: it must see what the caller's stream did meanwhile (new weights)
         hipError_t e = hipEventRecord(s->after, (hipStream_t)s->bound.after_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->after, 0);
         if (e != hipSuccess) return (int)e;
-        rc = session_launch(s);
+        if ((rc = session_launch(s))) return rc;
     }
-    if (!rc) rc = session_launch(s);                  // the kernel for the NEXT request: overlaps this one
-    if (rc) return rc;
     const int nw = s->continuous ? s->A : 1;          // action words; two tagged dwords each
     unsigned r[16];
     const unsigned* const reply = reinterpret_cast<const unsigned*>(mb->reply);
@@ -515,24 +532,19 @@ extern "C" int ppo_act_session_step_bound(ppo_act_session* s, int64_t row, uint6
         }
         if (all) break;
         const unsigned gave_up = __atomic_load_n(&mb->unserved, __ATOMIC_ACQUIRE);
-        if (gave_up != s->seen_unserved) {            // waiting kernels that left before the request came
-            s->inflight -= (int)(gave_up - s->seen_unserved);
+        if (gave_up != s->seen_unserved) {            // the waiting kernel left before the request came
             s->seen_unserved = gave_up;
-            if (s->inflight <= 0) {
-                s->inflight = 0;
-                if ((rc = session_launch(s))) return rc;
-            }
+            if ((rc = session_launch(s))) return rc;
         }
         if ((spins & 0xffff) == 0) {
             const hipError_t q = hipStreamQuery(s->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
             if (q == hipSuccess && (__atomic_load_n(&reply[0], __ATOMIC_RELAXED) & 0xffff0000u) != tag &&
                 __atomic_load_n(&mb->unserved, __ATOMIC_ACQUIRE) == s->seen_unserved)
-                return (int)hipErrorUnknown;          // every kernel ended, none served, none gave up
+                return (int)hipErrorUnknown;          // the kernel ended, it neither served nor gave up
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    --s->inflight;                                     // the kernel that served k
     unsigned* const out = (unsigned*)s->bound.action_out;
     for (int i = 0; i < nw; ++i) out[i] = (r[2 * i] & 0xffffu) | (r[2 * i + 1] << 16);
     return 0;
