@@ -194,21 +194,25 @@ int ppo_act_host(const float* params, int state_dim, int action_dim, int continu
                  void* action_row, float* logprob_row, float* value_row, void* host_action_out,
                  unsigned* host_ticket, unsigned ticket, void* stream);
 
-/* The same step with the kernel launch taken off the critical path.  A session keeps one kernel
- * launched AHEAD of its state: the kernel loads the weights, then polls a mailbox in page-locked
- * host memory (owned by the session) until the next request is posted, serves it and ends; it gives
- * up by itself after about wait_us microseconds, or when the session is drained.  _step posts the
- * request (state, rows, seed / rng_offset and action_var as in ppo_act), launches the kernel for the
- * step after, and returns when the action (int32, or action_dim floats) is in action_out (ordinary
- * host memory); when it returns, all four rows of the step are visible to every stream.  The
- * results are ppo_act's, bit for bit.  The session's kernels run on a stream of its own; the first
- * kernel after _create / _drain is ordered behind the work already enqueued on after_stream.
+/* The same step with launch, kernel start and weight load taken out of it.  A session keeps ONE kernel
+ * waiting: it loads the weights, then polls a mailbox in page-locked host memory (owned by the
+ * session) for requests and serves them one after the other; it ends by itself after about wait_us
+ * microseconds without a request, or when the session is drained, and a step that finds no kernel
+ * waiting launches one.  _step posts the request (state, rows, seed / rng_offset and action_var as in
+ * ppo_act) and returns when the action (int32, or action_dim floats) is in action_out (ordinary host
+ * memory); when it returns, all four rows of the step are visible to every stream.  The results are
+ * ppo_act's, bit for bit.  The session's kernels run on a stream of its own; a kernel launched after
+ * _create / _drain is ordered behind the work already enqueued on after_stream.
  * _drain withdraws the waiting kernel and waits for the session's stream: call it before the
  * weights behind `params` change, before the rows' storage moves, and before exit (_destroy does).
- * The waiting kernel loads its weights when it is launched, one step early: params_version is the
- * caller's count of writes to the vector behind `params` (any number that changes whenever the
- * contents do); a step whose params or params_version differ from those the waiting kernel was
- * launched under withdraws that kernel and is served by one launched now.
+ * The waiting kernel holds the weights it loaded at its launch and carries the buffer columns, the seed
+ * and the variance in its arguments: params_version is the caller's count of writes to the vector
+ * behind `params` (any number that changes whenever the contents do); a step whose params,
+ * params_version, columns, seed or variance differ from those the waiting kernel was launched under
+ * withdraws that kernel and is served by one launched now.  _step addresses rows by pointer: a call
+ * whose four rows are row r (0 <= r < 2^32) of the columns of the binding in force is served as that
+ * binding's step r, so a caller that walks down its buffer keeps its waiting kernel; any other call
+ * binds anew with its rows as row 0.
  * One session serves one caller thread.  No counterpart in the reference: PPO.py:175-198 pays a
  * full launch per step. */
 typedef struct ppo_act_session ppo_act_session;
@@ -221,9 +225,10 @@ int ppo_act_session_step(ppo_act_session* session, const float* params, uint64_t
 /* The same step with its unchanging arguments bound beforehand (a host loop's per-step cost is mostly
  * argument marshalling in the binding).  _bind stores the weights, their version, the variance, the
  * host state / action buffers, the seed, the four buffer columns (dense rows: state_dim floats; one
- * int32 or action_dim floats; one float; one float) and the stream the first kernel after a drain is
- * ordered behind; _step_bound(row, rng_offset) is ppo_act_session_step on row `row` of those columns.
- * Bind again whenever one of the bound things changes. */
+ * int32 or action_dim floats; one float; one float) and the stream a newly launched kernel is
+ * ordered behind; _step_bound(row, rng_offset), 0 <= row < 2^32, is ppo_act_session_step on row `row`
+ * of those columns.  Bind again whenever one of the bound things changes (the next step then replaces
+ * the waiting kernel). */
 int ppo_act_session_bind(ppo_act_session* session, const float* params, uint64_t params_version,
                          float action_var, const float* host_state, void* action_out, uint64_t seed,
                          float* states, void* actions, float* logprobs, float* values,

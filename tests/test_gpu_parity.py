@@ -749,9 +749,9 @@ def test_synthetic_rollout_equals_per_step_calls(eng, cont, S, A, N, T):
 def test_single_state_host_path_equals_batched_rows(eng, cont, mode, monkeypatch):
     """select_action(np.ndarray[S]) stores exactly what the batched call stores for the same states
     (the one-unit-per-lane VALU kernel reproduces the MFMA tile's fmaf chain), and returns the
-    reference's Python types.  session: kernels launched one step ahead that wait for the state in a
-    mailbox; session_slow_env: the env takes longer than the kernel waits, so every waiting kernel
-    gives up and the step is served by a fresh one; ticket: one launch per call (ppo_act_host)."""
+    reference's Python types.  session: a long-lived kernel that waits for each state in a mailbox;
+    session_slow_env: the env takes longer than the kernel waits, so every waiting kernel gives up
+    and the step is served by a fresh one; ticket: one launch per call (ppo_act_host)."""
     ppo, _ = eng
     monkeypatch.setenv("PPO_ACT_SESSION", "0" if mode == "ticket" else "1")
     monkeypatch.setenv("PPO_ACT_WAIT_US", "200" if mode == "session_slow_env" else "1000")
@@ -817,7 +817,7 @@ def test_single_state_session_survives_buffer_growth(eng):
 
 @pytest.mark.parametrize("cont", [False, True])
 def test_single_state_session_sees_in_place_weight_writes(eng, cont):
-    """The kernel that serves step k+1 is launched during step k and loads its weights then.  An
+    """The kernel that serves step k+1 was launched earlier and loaded its weights then.  An
     in-place write to policy_old's parameters between two steps - through the flat vector or through
     one of the nn.Linear views, outside update() / load() / load_state_dict() - must still be seen
     by the next step: its stored log-prob and value equal evaluate() under the NEW weights."""
@@ -848,6 +848,68 @@ def test_single_state_session_sees_in_place_weight_writes(eng, cont):
     agent.close()                        # idempotent
     with pytest.raises(ValueError):
         agent.select_action(np.zeros(1))         # a length-1 state is not broadcast into S inputs
+
+
+@pytest.mark.parametrize("cont,S,A", [(False, 63, 8), (True, 40, 3), (False, 30, 2), (True, 3, 1)])
+def test_session_step_by_pointer_equals_batched_act(eng, cont, S, A):
+    """ppo_act_session_step through the C-ABI (rows given by pointer, ordinary host memory for state and
+    action): rows walked in order, a jump within the same columns (served by the waiting kernel), other
+    columns (a new binding), a pause longer than the kernel waits.  Observations of
+    30, 40 and 63 values make the request two and three dwords per lane.  Every row equals ppo_act's
+    row for the same state and draw, bit for bit, and so does the action handed back."""
+    ppo, _lib = eng
+    L = _lib.lib()
+    torch.manual_seed(17)
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, cont, 0.5 if cont else None)
+    pol = agent.policy_old
+    n = 40
+    xs = np.random.default_rng(6).standard_normal((n, S)).astype(np.float32)
+
+    def columns():
+        return (torch.zeros((n, S), device="cuda"),
+                torch.zeros((n, A), device="cuda") if cont else torch.zeros((n,), dtype=torch.int32, device="cuda"),
+                torch.zeros((n,), device="cuda"), torch.zeros((n,), device="cuda"))
+
+    cols_a, cols_b = columns(), columns()
+    torch.cuda.synchronize()
+    sess = ctypes.c_void_p()
+    _lib.check(L.ppo_act_session_create(ctypes.byref(sess), S, A, int(cont), 300))
+    state = np.zeros(S, dtype=np.float32)
+    out = np.zeros(8, dtype=np.float32)
+    seed, stream = 4242, _lib.stream_ptr()
+    aw = (A if cont else 1) * 4
+    try:
+        def step(cols, row, off, var):
+            state[:] = xs[row]
+            _lib.check(L.ppo_act_session_step(
+                sess, pol.flat.data_ptr(), 1, var, state.ctypes.data, seed, off,
+                cols[0].data_ptr() + row * S * 4, cols[1].data_ptr() + row * aw, cols[2].data_ptr() + row * 4,
+                cols[3].data_ptr() + row * 4, out.ctypes.data, stream))
+            return out[:A].copy() if cont else int(out[:1].view(np.int32)[0])
+
+        plan = [(cols_a, r, 100 + r, pol._var_host) for r in (0, 1, 2, 3, 17, 18, 5)]
+        plan += [(cols_b, r, 200 + r, pol._var_host) for r in (7, 8, 9)]
+        plan += [(cols_a, 30, 300, pol._var_host)]
+        returned = []
+        for i, (cols, row, off, var) in enumerate(plan):
+            if i == 5:
+                time.sleep(0.002)     # the waiting kernel gives up (300 us)
+            returned.append(step(cols, row, off, var))
+        _lib.check(L.ppo_act_session_drain(sess))
+        for (cols, row, off, var), ret in zip(plan, returned):
+            a, lp, v = pol.act(torch.from_numpy(xs[row]).cuda(), _seed=seed, _offset=off)
+            assert torch.equal(cols[0][row].cpu(), torch.from_numpy(xs[row])), row
+            assert torch.equal(cols[2][row:row + 1], lp.reshape(1)), row
+            assert torch.equal(cols[3][row:row + 1], v.reshape(1)), row
+            if cont:
+                assert torch.equal(cols[1][row], a.reshape(-1)), row
+                assert np.array_equal(ret, a.reshape(-1).cpu().numpy()), row
+            else:
+                assert int(cols[1][row]) == int(a) == ret, row
+        # rows no step addressed stay untouched
+        assert float(cols_b[2][:7].abs().sum()) == 0.0 and float(cols_a[2][31:].abs().sum()) == 0.0
+    finally:
+        _lib.check(L.ppo_act_session_destroy(sess))
 
 
 @pytest.mark.parametrize("cont,S,A", [(False, 4, 2), (True, 24, 6), (False, 63, 8)])
