@@ -172,26 +172,60 @@ __device__ inline NetLds carve_net_lds(float* base, int S, int aout, bool bwd) {
     return L;
 }
 
-// Block-wide fill; caller synchronises afterwards.
+// Block-wide fill; caller synchronises afterwards.  Every global load of the first pass (8 elements of W1
+// and of W2 per thread - all of them for 512 threads - and the small tensors) is issued before the first
+// LDS store, so that the fill costs one memory latency instead of one per tensor and trip (the weights
+// were written by the previous launch: they come from beyond this XCD's L2).  BATCHED = false is the plain
+// form, one tensor and one trip after the other (same image).
+template <bool BATCHED = true>
 __device__ inline void fill_net_lds(const NetLds& L, const float* __restrict__ params,
                                     const NetLayout& P, int S, int A, int aout, bool bwd) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int rows1 = 2 * ks1_of(S);
-    for (int i = tid; i < rows1 * HID; i += nt) {
+    const int n1 = 2 * ks1_of(S) * HID, n2 = HID * HID, n3 = aout * HID;
+    auto w1_elem = [&](int i) {   // image row k (< S: input k; == S: bias b1; > S: zero), column = hidden unit
         const int k = i >> 6, o = i & 63;
-        float v = 0.f;
-        if (k < S) v = params[P.w1 + o * S + k];
-        else if (k == S) v = params[P.b1 + o];
-        L.w1t[i] = v * TANH_PRESCALE;
-    }
-    for (int i = tid; i < HID * HID; i += nt) {
-        const float v = params[P.w2 + i];  // W2[out = i>>6][in = i&63]
+        return k < S ? params[P.w1 + o * S + k] : (k == S ? params[P.b1 + o] : 0.f);
+    };
+    auto put_w1 = [&](int i, float v) { L.w1t[i] = v * TANH_PRESCALE; };
+    auto put_w2 = [&](int i, float v) {   // W2[out = i>>6][in = i&63]
         L.w2f[(i >> 6) * W2_LD + (i & 63)] = v * TANH_PRESCALE;
         if (bwd) L.w2b[(i & 63) * W2_LD + (i >> 6)] = v;
+    };
+    auto w3_elem = [&](int i) { return (i >> 6) < A ? params[P.w3 + i] : 0.f; };
+    if constexpr (!BATCHED) {
+        for (int i = tid; i < n1; i += nt) put_w1(i, w1_elem(i));
+        for (int i = tid; i < n2; i += nt) put_w2(i, params[P.w2 + i]);
+        for (int i = tid; i < HID; i += nt) L.b2[i] = params[P.b2 + i] * TANH_PRESCALE;
+        for (int i = tid; i < n3; i += nt) L.w3[i] = w3_elem(i);
+        for (int i = tid; i < aout; i += nt) L.b3[i] = i < A ? params[P.b3 + i] : 0.f;
+        return;
     }
-    for (int i = tid; i < HID; i += nt) L.b2[i] = params[P.b2 + i] * TANH_PRESCALE;
-    for (int i = tid; i < aout * HID; i += nt) L.w3[i] = (i >> 6) < A ? params[P.w3 + i] : 0.f;
-    for (int i = tid; i < aout; i += nt) L.b3[i] = i < A ? params[P.b3 + i] : 0.f;
+    constexpr int U = 8;
+    float r1[U], r2[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int i = tid + j * nt;
+        r1[j] = i < n1 ? w1_elem(i) : 0.f;
+        r2[j] = i < n2 ? params[P.w2 + i] : 0.f;
+    }
+    const float rb2 = tid < HID ? params[P.b2 + tid] : 0.f;
+    const float r3 = tid < n3 ? w3_elem(tid) : 0.f;
+    const float rb3 = tid < A ? params[P.b3 + tid] : 0.f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int i = tid + j * nt;
+        if (i < n1) put_w1(i, r1[j]);
+        if (i < n2) put_w2(i, r2[j]);
+    }
+    if (tid < HID) L.b2[tid] = rb2 * TANH_PRESCALE;
+    if (tid < n3) L.w3[tid] = r3;
+    if (tid < aout) L.b3[tid] = rb3;
+    // what the first pass did not reach (fewer than 512 threads)
+    for (int i = tid + U * nt; i < n1; i += nt) put_w1(i, w1_elem(i));
+    for (int i = tid + U * nt; i < n2; i += nt) put_w2(i, params[P.w2 + i]);
+    for (int i = tid + nt; i < HID; i += nt) L.b2[i] = params[P.b2 + i] * TANH_PRESCALE;
+    for (int i = tid + nt; i < n3; i += nt) L.w3[i] = w3_elem(i);
+    for (int i = tid + nt; i < aout; i += nt) L.b3[i] = i < A ? params[P.b3 + i] : 0.f;
 }
 
 // Layer 2 of the forward pass: Z2 = W2 H1 + b2 (prescaled), tanh.  H1 stays in registers as the B

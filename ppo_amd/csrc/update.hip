@@ -69,37 +69,66 @@ __device__ __forceinline__ int narrow_col(int c) {
 
 // Diagnostic build only (-DPPO_PHASE_STAMPS): per-phase s_memtime sums, one row of 16 counters per
 // wave, written to a buffer registered with ppo_debug_set_stamps().  Never compiled into the product.
-#if defined(PPO_PHASE_STAMPS) && defined(PPO_FWDBWD_SEEDED)
+#if defined(PPO_PHASE_STAMPS)
 static unsigned long long* g_stamp_buf = nullptr;
-#elif defined(PPO_PHASE_STAMPS)
-static unsigned long long* g_stamp_buf = nullptr;
+#ifndef PPO_FWDBWD_SEEDED
 extern "C" void ppo_debug_set_stamps(void* p) { g_stamp_buf = (unsigned long long*)p; }
+#endif
 #define STAMP_DECL unsigned long long st_acc[12] = {0}; unsigned long long st_prev = 0;
 #define STAMP_START { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[i] += _t - st_prev; st_prev = _t; __builtin_amdgcn_sched_barrier(0); }
 #define STAMP_FLUSH(a, wave) if ((a).stamps && (threadIdx.x & 63) == 0) { unsigned long long* row = (a).stamps + ((size_t)blockIdx.x * 8 + (wave)) * 16; for (int i = 0; i < 12; ++i) row[i] = st_acc[i]; }
+// wall-clock marks (100 MHz) of a workgroup's stages, slots 12..15 of every wave's row
+#define WG_MARK(a, i) if ((a).stamps && (threadIdx.x & 63) == 0) (a).stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
 #else
+#define WG_MARK(a, i)
 #define STAMP_DECL
 #define STAMP_START
 #define STAMP(i)
 #define STAMP_FLUSH(a, wave)
 #endif
 
-// Sum of per-lane partials over the 32 sample columns through `buf` (>= 32*CS_LD floats, private
-// to the calling wave): written as [register][lane], read back as 32 consecutive floats per hidden
-// unit; lane u returns unit u's total.  Fixed order, no cross-lane instructions.
+// Sum of per-lane partials over the 32 sample columns through `buf` (>= 16*CS_LD floats, private
+// to the calling wave): one accumulator tile at a time, written as [register][lane], read back as 32
+// consecutive floats per hidden unit by the half wave whose units the tile holds; lane u returns unit
+// u's total.  Fixed order, no cross-lane instructions (a wave's LDS operations execute in order).
+#define CS_FLOATS (16 * CS_LD)
+// (WHOLE: both tiles at once through a buffer of 32*CS_LD floats; the same sums)
+template <bool WHOLE = false>
 __device__ __forceinline__ float colsum(float* buf, const f32x16 (&v)[2], int lane) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) buf[(16 * t + r) * CS_LD + lane] = v[t][r];
     const int q = lane & 31;
-    const float* src = buf + (16 * (lane >> 5) + (q & 3) + 4 * (q >> 3)) * CS_LD + 32 * ((q >> 2) & 1);
+    if constexpr (WHOLE) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf[(16 * t + r) * CS_LD + lane] = v[t][r];
+        const float* src = buf + (16 * (lane >> 5) + (q & 3) + 4 * (q >> 3)) * CS_LD + 32 * ((q >> 2) & 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) acc += src[cc];
+        return acc;
+    }
+    const float* src = buf + ((q & 3) + 4 * (q >> 3)) * CS_LD + 32 * ((q >> 2) & 1);
     float acc = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < 32; ++cc) acc += src[cc];
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[r * CS_LD + lane] = v[t][r];
+        if ((lane >> 5) == t) {
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) acc += src[cc];
+        }
+    }
     return acc;
 }
+
+// The edges of a launch - staging the weights with every load in flight at once, the forward waves'
+// column sums ahead of the post-loop barrier - are worth 3 - 4 us per launch (-1.3 % per epoch at 524 288
+// samples of the CartPole shape, -12 % of a 1600-sample launch).  Observations of 16 - 31 values keep the
+// plain forms: with the short edges their TILE LOOP measured 1.2 % slower at 8.4 M samples of the
+// HalfCheetah shape (same instruction counts; the loop's register assignment comes out differently),
+// which is 20 times what the edges save there.
+__host__ __device__ constexpr bool fb_short_edges(int l1) { return l1 != 1; }
 
 // Everything one wave needs to know about its place in the workgroup.
 struct WaveCtx {
@@ -327,13 +356,18 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     }
     STAMP_START
 
-    __syncthreads();  // every wave is done with the tile loop
-    // per-lane partials -> per-unit sums through this pair's own LDS space
-    const float db2_u = colsum(dzs, gb2, lane);  // d/d b2[lane]
+    // per-lane partials -> per-unit sums, through the image of the forward pass's layer-2 weights: past
+    // the loop's last barrier no forward wave reads it any more (the backward waves never do), so this
+    // runs while the partner still works on the last tile
+    static_assert(FB_PAIRS * CS_FLOATS <= HID * W2_LD, "the four transposition buffers fit the W2 image");
+    constexpr bool EARLY = fb_short_edges(L1);
+    if constexpr (!EARLY) __syncthreads();   // (the plain form: after the partner, through the pair's hand-off space)
+    float* const cs = EARLY ? L.w2f + ctx.pair * CS_FLOATS : dzs;
+    const float db2_u = colsum<!EARLY>(cs, gb2, lane);   // d/d b2[lane]
     float dw3_u[L3_VALU ? AOUT : 1];              // d/d W3[k][lane] on the VALU path
     if constexpr (L3_VALU) {
 #pragma unroll
-        for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum(dzs, gW3v[k], lane);
+        for (int k = 0; k < AOUT; ++k) dw3_u[k] = colsum<!EARLY>(cs, gW3v[k], lane);
     }
 #pragma unroll
     for (int k = 0; k < AOUT; ++k) {
@@ -344,7 +378,7 @@ __device__ __forceinline__ void fwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) loss_acc += __shfl_xor(loss_acc, off);
-    __syncthreads();  // LDS (weights and transposition space) is free from here on
+    __syncthreads();  // every wave is done with the tile loop: LDS (weights and hand-off space) is free from here on
     const int o_b2 = ctx.P.b2 - ctx.base, o_w3 = ctx.P.w3 - ctx.base, o_b3 = ctx.P.b3 - ctx.base,
               o_loss = ctx.P.n;
     RED_PUT(o_b2 + lane, db2_u);
@@ -543,7 +577,6 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
         }
         __syncthreads();  // buffers of this tile are complete
         STAMP(2)
-
         // S >= 32 (128 accumulator registers): the layer-2 wgrad runs FIRST, so that dH1's 32 registers
         // are not live across it, and the layer-1 wgrad's 32 operand registers are fetched only after
         // it (their latency passes under the dgrad)
@@ -608,8 +641,8 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
     }
     STAMP_START
 
-    __syncthreads();  // every wave is done with the tile loop
-    __syncthreads();  // LDS (weights and transposition space) is free from here on
+    if constexpr (!fb_short_edges(L1)) __syncthreads();
+    __syncthreads();  // every wave is done with the tile loop: LDS (weights and hand-off space) is free from here on
     const int o_w1 = ctx.P.w1 - ctx.base, o_b1 = ctx.P.b1 - ctx.base, o_w2 = ctx.P.w2 - ctx.base;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -646,6 +679,7 @@ __device__ __forceinline__ void bwd_wave(const FwdBwdArgs& a, const WaveCtx& ctx
 
 template <int HEAD, int AOUT, int L1>
 __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
+    WG_MARK(a, 12)
     WaveCtx ctx;
     ctx.S = a.S;
     ctx.A = HEAD == HEAD_VALUE ? 1 : a.A;
@@ -672,19 +706,22 @@ __device__ __forceinline__ void run_role(const FwdBwdArgs& a, float* smem) {
     ctx.tstride = (int64_t)nwg * FB_PAIRS;
     ctx.tile0 = (int64_t)wg * FB_PAIRS + ctx.pair;
     ctx.n_iter = (int)((ctx.n_tiles + ctx.tstride - 1) / ctx.tstride);
-    fill_net_lds(ctx.L, a.params, ctx.P, a.S, ctx.A, AOUT, true);
+    fill_net_lds<fb_short_edges(L1)>(ctx.L, a.params, ctx.P, a.S, ctx.A, AOUT, true);
     for (int i = threadIdx.x; i < FB_PAIRS * 9 * DT_LD; i += FB_THREADS)
         stg[(i / (9 * DT_LD)) * PAIR_FLOATS + 2 * STG_MAT + i % (9 * DT_LD)] = 0.f;
     __syncthreads();
+    WG_MARK(a, 13)
 
     if (wave < FB_PAIRS) fwd_wave<HEAD, AOUT, L1>(a, ctx);
     else bwd_wave<L1>(a, ctx);
+    WG_MARK(a, 14)
 
     // (both wave kinds end on the barrier that completes the four per-pair arrays)
     float* dst = HEAD == HEAD_VALUE ? a.partial_critic + (size_t)wg * a.stride_critic
                                     : a.partial_actor + (size_t)wg * a.stride_actor;
     for (int i = threadIdx.x; i < red_stride; i += FB_THREADS)
         dst[i] = ((smem[i] + smem[red_stride + i]) + smem[2 * red_stride + i]) + smem[3 * red_stride + i];
+    WG_MARK(a, 15)
 }
 
 template <bool CONT, int AMAX, int L1>
