@@ -815,6 +815,33 @@ def test_single_state_session_survives_buffer_growth(eng):
         assert torch.equal(a, b)
 
 
+def test_single_state_session_request_numbers_wrap(eng):
+    """70 000 single-state steps through one session: the 16-bit request number carried by every
+    mailbox dword wraps once, two pauses make the waiting kernel give up and be replaced, the buffer
+    grows several times.  Every stored row equals evaluate() of the stored state and action bit for
+    bit, the states are the inputs, the returned actions are the stored ones."""
+    ppo, _ = eng
+    S, A, n = 6, 3, 70000
+    torch.manual_seed(9)
+    agent = ppo.PPO(S, A, 3e-4, 1e-3, 0.99, 2, 0.2, False, None)
+    xs = np.random.default_rng(12).standard_normal((n, S)).astype(np.float32)
+    acts = np.empty(n, dtype=np.int64)
+    for i in range(n):
+        if i in (30000, 65600):
+            time.sleep(0.003)
+        acts[i] = agent.select_action(xs[i])
+    agent._act_drain()
+    b = agent.buffer
+    st, ac = b.rows("states", 0, n), b.rows("actions", 0, n)
+    with torch.no_grad():
+        lp, val, _ = agent.policy_old.evaluate(st, ac)
+    assert torch.equal(st.cpu(), torch.from_numpy(xs))
+    assert np.array_equal(acts, ac.cpu().numpy().astype(np.int64))
+    assert torch.equal(lp, b.rows("logprobs", 0, n))
+    assert torch.equal(val.reshape(-1), b.rows("state_values", 0, n))
+    agent.close()
+
+
 @pytest.mark.parametrize("cont", [False, True])
 def test_single_state_session_sees_in_place_weight_writes(eng, cont):
     """The kernel that serves step k+1 was launched earlier and loaded its weights then.  An
