@@ -10,7 +10,7 @@
 //   0,4,1,5,2,6,3,7 | 8,12,...;  out layer: the four partial sums of out_layer_act.
 // The activation a lane needs from another lane comes by v_readlane (layer 2) or through 64 floats
 // of LDS (out layer).  Wave 0 = actor (+ head, sampling, the host copy of the action and the
-// completion ticket), wave 1 = critic.
+// completion notice), wave 1 = critic.
 //
 // Two ways to hand it a state:
 //  * ppo_act_host: the state travels in the launch's arguments; the host spins on a ticket word in

@@ -535,7 +535,7 @@ class PPO:
 
         # engine state
         self._rng_seed = None      # drawn from torch's generator on first use (honours torch.manual_seed)
-        self._act_session = None   # single-env protocol: session of kernels launched ahead, made on first use
+        self._act_session = None   # single-env protocol: session with a long-lived act kernel, made on first use
         self._host_step = None     # ... and its per-step closure
         self._pin = None           # ... or, with PPO_ACT_SESSION=0, the page-locked staging of ppo_act_host
         # weak: the hooks must not keep this object alive (a cycle would leave the session to the cycle
@@ -641,7 +641,7 @@ class PPO:
 
     def _select_action_host(self, state):
         """The reference's protocol, one host state per call (PPO.py:175-198).  Default: a session
-        of act kernels launched one step ahead, which wait for the state in a page-locked mailbox
+        whose long-lived act kernel waits for each state in a page-locked mailbox
         (ppo_act_session_step) - no launch and no stream wait between "state known" and "action
         known".  PPO_ACT_SESSION=0: one launch per call with the state in its arguments, and a spin
         on a ticket word the kernel writes next to the action (ppo_act_host)."""
