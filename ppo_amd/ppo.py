@@ -116,7 +116,19 @@ class _HostColumn(list):
         self._buf = buf
         self._name = name
 
-    def append(self, value):
+    # train.py:180-181 appends one scalar per step: that case is one dictionary lookup on the exact type
+    # (torch.Tensor's instance check is a Python-level call and cost more than the append itself).
+    # Python scalars go in as they are, numpy scalars as the Python scalar of the same value.
+    _FAST = {float: None, bool: None, int: None, np.float32: float, np.float64: float, np.bool_: bool}
+
+    def append(self, value, _fast=_FAST, _append=list.append):
+        conv = _fast.get(type(value), _fast)
+        if conv is None:
+            _append(self, value)
+            return
+        if conv is not _fast:
+            _append(self, conv(value))
+            return
         if isinstance(value, (torch.Tensor, np.ndarray)) and getattr(value, "ndim", 0) >= 1 \
                 and value.shape[0] > 1:
             self._buf._append_step(self._name, value)
