@@ -273,6 +273,14 @@ int ppo_cartpole_step(double* state, int* steps, unsigned* episodes, float* fin_
                       const int* actions, float* obs_out, float* rewards_out,
                       uint8_t* terminals_out, int64_t n_envs, int max_episode_steps, uint64_t seed,
                       void* stream);
+/* env.step(action) of ONE env (n_envs = 1) as the reference's loop calls it (train.py:177): the action
+ * (0 or 1) rides in the launch's arguments; host_out (6 floats: observation, reward, terminal flag as
+ * 0.0 / 1.0) and host_ticket (one word) are PAGE-LOCKED host buffers the kernel writes directly; the
+ * call returns when `ticket` (any value other than the word's current one) is in *host_ticket.  One
+ * launch, no copy commands, no stream wait; the same step as ppo_cartpole_step, bit for bit. */
+int ppo_cartpole_step_host(double* state, int* steps, unsigned* episodes, float* fin_sum, int* fin_cnt,
+                           int action, float* host_out, unsigned* host_ticket, unsigned ticket,
+                           int max_episode_steps, uint64_t seed, void* stream);
 
 /* n_steps lockstep steps of the policy on the device-side CartPole envs, enqueued by one call: row t
  * of the time-major buffers (states [n_steps*n_envs, 4], actions int32, logprobs, values, rewards,

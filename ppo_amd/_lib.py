@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to before d
 HERE = os.path.dirname(os.path.abspath(__file__))
 # PPO_HIP_LIB: diagnostic builds of the same sources (python -m ppo_amd.build --variant ...)
 LIB_PATH = os.environ.get("PPO_HIP_LIB") or os.path.join(HERE, "libppo_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _SIGNATURES = {
     "ppo_hip_abi_version": (c_int, []),
@@ -57,6 +57,8 @@ _SIGNATURES = {
                                    c_uint64, c_void_p]),
     "ppo_cartpole_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int64, c_int, c_uint64, c_void_p]),
+    "ppo_cartpole_step_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_void_p, ctypes.c_uint, c_int, c_uint64, c_void_p]),
     "ppo_update_epochs": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_double, c_double, c_double, c_double, c_double, c_void_p,

@@ -94,3 +94,58 @@ extern "C" int ppo_cartpole_step(double* state, int* steps, unsigned* episodes, 
     return (int)hipGetLastError();
 }
 
+
+// env.step(action) of ONE env as the reference's loop calls it (train.py:177): the action travels in
+// the launch's arguments, observation / reward / terminal flag are written straight into page-locked
+// host memory, then a ticket word on which the host spins: one launch, no copy commands, no stream
+// wait.  The same step as cartpole_step_kernel's thread 0, bit for bit.
+__global__ __launch_bounds__(64) void cartpole_step_host_kernel(const CartPoleArgs a, int action,
+                                                                unsigned* host_ticket, unsigned ticket) {
+    if (threadIdx.x != 0) return;
+    double s[4] = {a.state[0], a.state[1], a.state[2], a.state[3]};
+    const bool fell = cartpole_advance(s, action);
+    const int steps = a.steps[0] + 1;
+    const bool done = fell || steps >= a.max_steps;
+    a.rewards[0] = 1.0f;
+    a.obs[5] = done ? 1.0f : 0.0f;        // host record: [obs 0..3 | reward | terminal flag]
+    if (done) {
+        if (a.fin_sum) a.fin_sum[0] += (float)steps;
+        if (a.fin_cnt) a.fin_cnt[0] += 1;
+        cartpole_reset_one(a, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a.state[k] = s[k];
+            a.obs[k] = (float)s[k];
+        }
+        a.steps[0] = steps;
+    }
+    __threadfence_system();
+    __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int ppo_cartpole_step_host(double* state, int* steps, unsigned* episodes, float* fin_sum,
+                                      int* fin_cnt, int action, float* host_out, unsigned* host_ticket,
+                                      unsigned ticket, int max_episode_steps, uint64_t seed, void* stream) {
+    if (!state || !steps || !episodes || !host_out || !host_ticket || max_episode_steps < 1 ||
+        (action != 0 && action != 1))
+        return PPO_E_BADARG;
+    if (__atomic_load_n(host_ticket, __ATOMIC_ACQUIRE) == ticket) return PPO_E_BADARG;
+    CartPoleArgs a{};
+    a.state = state; a.steps = steps; a.episodes = episodes; a.fin_sum = fin_sum; a.fin_cnt = fin_cnt;
+    a.obs = host_out; a.rewards = host_out + 4; a.n = 1; a.max_steps = max_episode_steps; a.seed = seed;
+    hipStream_t st = (hipStream_t)stream;
+    cartpole_step_host_kernel<<<1, 64, 0, st>>>(a, action, host_ticket, ticket);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    // spin on the ticket; every so often ask the stream, so that a kernel that ended without writing it
+    // (a fault) surfaces as its error instead of a hang
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(host_ticket, __ATOMIC_ACQUIRE) == ticket) return 0;
+        if ((spins & 0xffff) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return __atomic_load_n(host_ticket, __ATOMIC_ACQUIRE) == ticket ? 0 : (int)hipErrorUnknown;
+            if (q != hipErrorNotReady) return (int)q;
+        }
+    }
+}

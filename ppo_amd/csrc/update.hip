@@ -1202,7 +1202,7 @@ extern "C" int ppo_update_epochs(float* params, int state_dim, int action_dim, i
     return 0;
 }
 
-extern "C" int ppo_hip_abi_version(void) { return 9; }
+extern "C" int ppo_hip_abi_version(void) { return 10; }
 
 extern "C" const char* ppo_hip_strerror(int code) {
     switch (code) {

@@ -84,6 +84,15 @@ class CartPoleVecEnv(_VecEnv):
         self._episodes = torch.zeros(n, dtype=torch.int32, device=d)
         self.finished_return_sum = torch.zeros(n, dtype=torch.float32, device=d)
         self.finished_count = torch.zeros(n, dtype=torch.int32, device=d)
+        if self.numpy_api:
+            # [obs 0..3 | reward | terminal flag | ticket word | pad]: what ppo_cartpole_step_host writes
+            self._pin_step = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._pin_step_np = self._pin_step.numpy()
+            self._ticket = 0
+            self._step_host = _lib.lib().ppo_cartpole_step_host
+            p = self._pin_step.data_ptr()
+            self._step_host_args = (self._state.data_ptr(), self._steps.data_ptr(), self._episodes.data_ptr(),
+                                    self.finished_return_sum.data_ptr(), self.finished_count.data_ptr(), p, p + 24)
 
     def reset(self):
         _lib.check(_lib.lib().ppo_cartpole_reset(
@@ -96,10 +105,16 @@ class CartPoleVecEnv(_VecEnv):
         """action: int (numpy_api) or an [N] integer device tensor.  The *_out tensors let a caller
         have the results written straight into its rollout buffer rows."""
         if self.numpy_api:
-            self._pin_act_np[0] = int(action)
-            self._act_dev.copy_(self._pin_act, non_blocking=True)
-            action = self._act_dev
-        elif action.dtype != torch.int32:
+            # the reference's per-step protocol: one launch with the action in its arguments; the kernel
+            # writes observation, reward and flag into page-locked memory and then a ticket word
+            self._ticket = ticket = (self._ticket % 0x7fffffff) + 1
+            rc = self._step_host(*self._step_host_args[:5], int(action), *self._step_host_args[5:7], ticket,
+                                 self.max_episode_steps, self._seed, torch.cuda.current_stream().cuda_stream)
+            if rc:
+                _lib.check(rc)
+            rec = self._pin_step_np
+            return rec[:4].copy(), float(rec[4]), bool(rec[5] != 0.0), {}
+        if action.dtype != torch.int32:
             action = action.to(torch.int32)
         obs = self._obs if obs_out is None else obs_out
         rew = self._rew if reward_out is None else reward_out

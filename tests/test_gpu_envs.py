@@ -67,6 +67,31 @@ def test_single_env_reference_protocol(envs):
     assert env.observation_space.shape == (4,) and env.action_space.n == 2
 
 
+def test_single_env_host_step_equals_the_lockstep_kernel(envs):
+    """The single-env protocol's step (one launch, action in the arguments, results and a ticket word
+    written into page-locked memory: ppo_cartpole_step_host) is the lockstep kernel's step for env 0, bit
+    for bit, over 1500 steps with resets (falls and the 500-step limit)."""
+    import torch
+    one = envs.make("CartPole-v1")
+    ref = envs.CartPoleVecEnv(1, numpy_api=False)
+    one.seed(77)
+    ref.seed(77)
+    s = one.reset()
+    assert np.array_equal(s, ref.reset().cpu().numpy()[0])
+    rng = np.random.default_rng(5)
+    n_done = 0
+    for t in range(1500):
+        # a balancing policy most of the time, so that some episodes reach the step limit
+        a = int(s[2] + 0.5 * s[3] > 0) if rng.random() < 0.97 else int(rng.integers(0, 2))
+        s, r, d, _ = one.step(a)
+        o2, r2, d2, _ = ref.step(torch.tensor([a], dtype=torch.int32, device="cuda"))
+        assert np.array_equal(s, o2.cpu().numpy()[0]), t
+        assert r == float(r2[0]) and d == bool(d2[0]), t
+        n_done += d
+    assert n_done >= 2
+    assert one.pop_episode_stats() == ref.pop_episode_stats()
+
+
 def test_train_synth_single_env_call_sequence(envs, tmp_path):
     """The per-step driver (train.py's call sequence) runs, logs in the reference's CSV format and
     writes a checkpoint the evaluation driver loads."""
