@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppo_hip.so")
 LIB_SYM = os.path.join(HERE, "libppo_hip_sym.so")
+FASTCALL = os.path.join(HERE, "_fastcall.so")          # CPython extension (csrc/fastcall.c), plain C
 SOURCES = ["scan.hip", "act.hip", "act_one.hip", "update.hip", "update_vjp.hip", "env.hip", "rollout.hip"]
 SYM_SOURCES = ["update_sym.hip"]             # + update.hip compiled with -DPPO_WITH_SYM
 HEADERS = ["ppo_common.h", "update_common.h", os.path.join("..", "..", "include", "ppo_hip.h")]
@@ -51,6 +52,21 @@ def _link(objs, lib, verbose):
     subprocess.check_call(cmd)
 
 
+def build_fastcall(force=False, verbose=True):
+    """The ctypes-free per-step binding (csrc/fastcall.c): a CPython extension compiled with the host C
+    compiler against this interpreter's headers; it links against nothing else."""
+    import sysconfig
+    src = os.path.join(CSRC, "fastcall.c")
+    if not force and os.path.exists(FASTCALL) and os.path.getmtime(FASTCALL) >= os.path.getmtime(src):
+        return FASTCALL
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-Wall", "-I" + sysconfig.get_paths()["include"],
+           src, "-o", FASTCALL]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return FASTCALL
+
+
 def build(force=False, verbose=True, variant=None, extra_flags=()):
     """Compile every HIP source for gfx950 and link the C-ABI shared libraries.  Returns the product
     library's path; build.last_action says what happened ("compiled" or "up to date").
@@ -66,6 +82,7 @@ def build(force=False, verbose=True, variant=None, extra_flags=()):
         lib = os.path.join(HERE, f"libppo_hip_{variant}.so")
         _link([obj(s) for s in srcs], lib, verbose)
         return lib
+    build_fastcall(force, verbose)
     if not force and not _stale(LIB, SOURCES) and not _stale(LIB_SYM, SOURCES + SYM_SOURCES):
         build.last_action = "up to date"
         return LIB

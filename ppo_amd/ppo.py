@@ -23,6 +23,10 @@ import torch.nn as nn
 
 from . import _lib
 from . import dist as _dist
+try:
+    from . import _fastcall   # optional: the ctypes-free per-step binding (python -m ppo_amd.build makes it)
+except ImportError:
+    _fastcall = None
 
 ################################## set device ##################################
 print("============================================================================================")
@@ -725,6 +729,13 @@ class PPO:
         raw_stream = torch._C._cuda_getCurrentRawStream
         dev_index = device.index or 0
         bound = [None, None, None, None]       # version, variance, the columns' address table, stream
+        # the per-step call without ctypes where the extension is built (csrc/fastcall.c): it takes the
+        # observation through the buffer protocol, converts it into the page-locked state buffer, calls
+        # ppo_act_session_step_bound and hands back the discrete action
+        fast = None
+        if _fastcall is not None and os.environ.get("PPO_FASTCALL", "1") != "0":
+            fast = _fastcall.Stepper(ctypes.cast(step, ctypes.c_void_p).value, sess.value, state_ptr, act_ptr,
+                                     self.state_dim, cont).step
 
         def rebind(version, var, ra, stream):
             for col, width in (("states", self.state_dim * 4), ("actions", (self.action_dim if cont else 1) * 4),
@@ -735,22 +746,33 @@ class PPO:
             bound[:] = [version, var, ra, stream]
 
         def host_step(state):
-            if state.shape != want_shape:
-                raise ValueError(f"select_action: state of shape {state.shape}, expected {want_shape}")
-            state_np[:] = state
             lo = cnt["states"]
             if lo >= b._cap:
                 b.reserve(lo + 1)
-            cnt["states"] = cnt["actions"] = cnt["logprobs"] = cnt["state_values"] = lo + 1
-            self._rng_offset = off = self._rng_offset + 1
             # flat._version counts the in-place writes to the weights (through any of their views): a
             # write since the waiting kernel was launched makes the library replace that kernel
             version, var, ra = flat._version, pol._var_host, b._row_addr
             if version != bound[0] or var != bound[1] or ra is not bound[2]:
                 rebind(version, var, ra, raw_stream(dev_index))
+            off = self._rng_offset + 1
+            if fast is not None:
+                try:
+                    act = fast(state, lo, off)
+                except RuntimeError as e:
+                    _lib.check(e.args[0])
+                    raise
+                if act is not NotImplemented:
+                    cnt["states"] = cnt["actions"] = cnt["logprobs"] = cnt["state_values"] = lo + 1
+                    self._rng_offset = off
+                    return act_np.copy() if cont else act
+            if state.shape != want_shape:
+                raise ValueError(f"select_action: state of shape {state.shape}, expected {want_shape}")
+            state_np[:] = state
             rc = step(sess, lo, off)
             if rc:
                 _lib.check(rc)
+            cnt["states"] = cnt["actions"] = cnt["logprobs"] = cnt["state_values"] = lo + 1
+            self._rng_offset = off
             if cont:
                 return act_np.copy()
             return int(act_int[0])

@@ -744,7 +744,7 @@ def test_synthetic_rollout_equals_per_step_calls(eng, cont, S, A, N, T):
         assert torch.equal(a, bb), c
 
 
-@pytest.mark.parametrize("mode", ["session", "session_slow_env", "ticket"])
+@pytest.mark.parametrize("mode", ["session", "session_ctypes", "session_slow_env", "ticket"])
 @pytest.mark.parametrize("cont", [False, True])
 def test_single_state_host_path_equals_batched_rows(eng, cont, mode, monkeypatch):
     """select_action(np.ndarray[S]) stores exactly what the batched call stores for the same states
@@ -754,6 +754,7 @@ def test_single_state_host_path_equals_batched_rows(eng, cont, mode, monkeypatch
     and the step is served by a fresh one; ticket: one launch per call (ppo_act_host)."""
     ppo, _ = eng
     monkeypatch.setenv("PPO_ACT_SESSION", "0" if mode == "ticket" else "1")
+    monkeypatch.setenv("PPO_FASTCALL", "0" if mode == "session_ctypes" else "1")   # the per-step binding: extension / ctypes
     monkeypatch.setenv("PPO_ACT_WAIT_US", "200" if mode == "session_slow_env" else "1000")
     S, A = (24, 4) if cont else (8, 4)
     xs = np.random.default_rng(8).standard_normal((6, S)).astype(np.float32)

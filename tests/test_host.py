@@ -287,3 +287,35 @@ def test_resume_checkpoint_round_trip(tmp_path):
     assert len(torch.load(str(tmp_path / "ref.pth"))) == 12
     with pytest.raises(ValueError):
         b.load_resume(str(tmp_path / "ref.pth"))
+
+
+def test_fastcall_extension_marshals_like_the_ctypes_binding():
+    """The ctypes-free per-step binding (ppo_amd/csrc/fastcall.c), driven on the CPU with a stand-in for
+    ppo_act_session_step_bound: float64 / float32 vectors land in the state buffer as float32, row and
+    offset arrive unchanged (64 bits), the discrete action comes back as an int (None for a continuous
+    policy), a library error code is raised, and anything it cannot take (wrong length, list, strided,
+    2-D, integer dtype) is declined with NotImplemented so that the caller's ctypes path runs instead."""
+    import ctypes
+    from ppo_amd import _fastcall
+    calls = []
+    proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64)
+    stand_in = proto(lambda sess, row, off: (calls.append((sess, row, off)), -2 if row == 7 else 0)[1])
+    fn = ctypes.cast(stand_in, ctypes.c_void_p).value
+    state = np.zeros(4, dtype=np.float32)
+    act = np.array([5, 0], dtype=np.int32)
+    st = _fastcall.Stepper(fn, 1234, state.ctypes.data, act.ctypes.data, 4, False)
+    assert st.step(np.array([1.0, 2.0, 3.0, 0.1]), 3, 99) == 5
+    assert np.array_equal(state, np.array([1.0, 2.0, 3.0, 0.1], dtype=np.float32)) and calls[-1] == (1234, 3, 99)
+    assert st.step(np.array([4, 3, 2, 1], dtype=np.float32), 2 ** 40, 2 ** 63 + 5) == 5
+    assert np.array_equal(state, [4, 3, 2, 1]) and calls[-1] == (1234, 2 ** 40, 2 ** 63 + 5)
+    n = len(calls)
+    for bad in (np.zeros(3), [1, 2, 3, 4], np.zeros((4, 1)), np.zeros(8)[::2], np.zeros(4, dtype=np.int64)):
+        assert st.step(bad, 0, 0) is NotImplemented
+    assert len(calls) == n
+    with pytest.raises(RuntimeError) as e:
+        st.step(np.zeros(4), 7, 0)
+    assert e.value.args == (-2,)
+    cont = _fastcall.Stepper(fn, 1, state.ctypes.data, act.ctypes.data, 4, True)
+    assert cont.step(np.zeros(4), 1, 1) is None
+    with pytest.raises(ValueError):
+        _fastcall.Stepper(0, 1, 2, 3, 4, False)
