@@ -122,7 +122,7 @@ _watchdog_file = None
 
 # the other BASELINE.json configurations, measured after the headline one by the default single-GPU run
 # (a few iterations each) and reported under "other_configs" of the same JSON line
-OTHER_CONFIGS = (("c5", 2, 1), ("c1", 3, 1), ("c2", 3, 1), ("c3", 3, 1))   # (config, steps, warmup)
+OTHER_CONFIGS = (("c5", 2, 1), ("c1", 8, 2), ("c2", 8, 2), ("c3", 5, 2))   # (config, steps, warmup)
 
 
 def measure(config_key, cfg, steps, warmup, world, rank, custom_shape, with_cpu, cpu_threads):
