@@ -7,6 +7,7 @@
 #include <csignal>
 #include <cstdio>
 #include <ctime>
+#include <immintrin.h>
 static sigjmp_buf jb;
 static void on_segv(int) { siglongjmp(jb, 1); }
 static double now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
@@ -17,7 +18,7 @@ __global__ void waiter(volatile unsigned* box, unsigned* reply_host, unsigned wa
     __hip_atomic_store(reply_host, it < limit ? want : 0xdeadu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-static void try_kind(const char* name, unsigned* dev) {
+static void try_kind(const char* name, unsigned* dev, bool flush = false) {
     unsigned* reply;
     hipHostMalloc((void**)&reply, 64, hipHostMallocDefault);
     signal(SIGSEGV, on_segv);
@@ -31,6 +32,7 @@ static void try_kind(const char* name, unsigned* dev) {
         timespec ts{0, 200000}; nanosleep(&ts, nullptr);          // let it start polling
         const double t0 = now_us();
         __atomic_store_n(dev, (unsigned)i, __ATOMIC_RELEASE);
+        if (flush) _mm_sfence();                                   // a write-combining mapping holds the store back otherwise
         while (__atomic_load_n(reply, __ATOMIC_ACQUIRE) == 0) {}
         tot += now_us() - t0;
         bad += *reply != (unsigned)i;
@@ -48,5 +50,8 @@ int main() {
     try_kind("page-locked host memory (kernel polls over PCIe)", host);
     if (e == hipSuccess) try_kind("fine-grained device memory", fine);
     try_kind("hipMalloc device memory", coarse);
+    if (e == hipSuccess) try_kind("fine-grained device memory, sfence after the store", fine, true);
+    try_kind("hipMalloc device memory, sfence after the store", coarse, true);
+    try_kind("page-locked host memory, sfence after the store", host, true);
     return 0;
 }
